@@ -1,0 +1,144 @@
+/*
+ * ptk.h -- C ABI of libptk, the MI355X render core that stands in for the
+ * Godot RenderingDevice calls made by the reference's PTWorkDispatcher /
+ * PTRenderer for the path-tracing compute dispatch.
+ *
+ * Every entry point names the reference call site it replaces (paths relative
+ * to the reference checkout).  All pointers are host pointers; the caller owns
+ * them and the library copies before returning (PackedByteArray semantics).
+ * Handles are opaque non-zero 64-bit values (the role Godot's RID plays); 0
+ * means failure.  Functions returning int return 0 on success and a negative
+ * PTK_E_* code on failure; ptk_last_error() then holds a message.  Nothing
+ * here aborts the process.  One context = one GPU + one HIP stream; calls on a
+ * context are not re-entrant (Godot drives them from its main thread).
+ */
+#ifndef PTK_H
+#define PTK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ptk_ctx ptk_ctx;
+
+enum {
+    PTK_OK = 0,
+    PTK_E_INVALID = -1,     /* bad argument / unknown handle */
+    PTK_E_HIP = -2,         /* a HIP runtime call failed */
+    PTK_E_UNSUPPORTED = -3, /* scene outside what the kernels accept (e.g. node wider than 8) */
+    PTK_E_STATE = -4        /* a required buffer is not bound */
+};
+
+/* (set, binding) contract of shaders/ray_tracer.comp:364-414 and
+ * proprietary_dataclasses/pt_work_dispatcher.gd:76-109. */
+enum {
+    PTK_SET_IMAGE = 0,
+    PTK_SET_OBJECT = 2,   /* bindings: 0 materials, 1 spheres, 2 planes, 3 triangles */
+    PTK_SET_BVH = 3,      /* bindings: 0 nodes, 1 object ids */
+    PTK_SET_TRIANGLE = 4, /* bindings: 0 vertex, 1 uv, 2 index (bound, never read by the kernel) */
+    PTK_SET_TEXTURE = 5,
+    PTK_SET_TRANSFORM = 6 /* binding 0: world->mesh matrices */
+};
+
+/* PTBVHTree.BVHType, proprietary_dataclasses/bvh_trees/pt_bvh_tree.gd:40-46 */
+enum { PTK_BVH_EMPTY = 0, PTK_BVH_X_SORTED = 1, PTK_BVH_Y_SORTED = 2, PTK_BVH_Z_SORTED = 3, PTK_BVH_XYZ_SORTED = 4 };
+
+/* Replaces RenderingServer.create_local_rendering_device() /
+ * get_rendering_device(), pt_work_dispatcher.gd:146-160. */
+ptk_ctx* ptk_create(int device_ordinal);
+/* Replaces PTWorkDispatcher.free_rids() for the whole device, pt_work_dispatcher.gd:448-454. */
+void ptk_destroy(ptk_ctx* ctx);
+/* Error text of the last failed call on ctx (ctx may be NULL after a failed ptk_create). */
+const char* ptk_last_error(ptk_ctx* ctx);
+
+/* Replaces shader_compile_spirv_from_source + shader_create_from_spirv +
+ * compute_pipeline_create (pt_work_dispatcher.gd:436-445) fed by
+ * PTUtils.load_shader (pt_utils.gd:140-195): selects the precompiled kernel
+ * variant.  bvh_order = text-replaced `order` constant; refraction_mode,
+ * use_emission, early_t_break = the shader's compile-time switches
+ * (ray_tracer.comp:84,92,96).  proc_tex_paths[i] is the texture_path of the
+ * scene's procedural texture with function index i+1; only the two shipped
+ * files (checker_board.comp, checker_board_spatial.comp) are accepted. */
+int ptk_configure(ptk_ctx* ctx, int bvh_order, int refraction_mode, int use_emission, int early_t_break,
+                  const char* const* proc_tex_paths, int n_paths);
+
+/* Replaces rd.storage_buffer_create + RDUniform binding + uniform_set_create,
+ * pt_work_dispatcher.gd:642-653 and :408-433.  Creating a buffer for a
+ * (set, binding) that already has one rebinds the slot (the old handle stays
+ * valid until freed), as PTWorkDispatcher does when it grows a buffer
+ * (:511-637). */
+uint64_t ptk_buffer_create(ptk_ctx* ctx, int set, int binding, const void* bytes, size_t nbytes);
+/* Replaces rd.buffer_update, proprietary_dataclasses/pt_renderer.gd:664-697,771-788. */
+int ptk_buffer_update(ptk_ctx* ctx, uint64_t buffer, size_t offset, const void* bytes, size_t nbytes);
+/* Replaces rd.buffer_get_data (used by the reference only while debugging); reads a buffer back. */
+int ptk_buffer_read(ptk_ctx* ctx, uint64_t buffer, size_t offset, void* dst, size_t nbytes);
+
+/* Replaces PTWorkDispatcher._create_image_buffer, pt_work_dispatcher.gd:374-405:
+ * an rgba32f storage image bound at (0,0).  Contents start as zeros. */
+uint64_t ptk_image_create(ptk_ctx* ctx, int width, int height);
+/* Replaces rd.texture_get_data(image, 0), pt_renderer.gd:327: width*height*16 bytes. */
+int ptk_image_read(ptk_ctx* ctx, uint64_t image, void* dst, size_t nbytes);
+/* Replaces rd.texture_update on the image (created with CAN_UPDATE, pt_work_dispatcher.gd:375-382). */
+int ptk_image_update(ptk_ctx* ctx, uint64_t image, const void* src, size_t nbytes);
+
+/* Replaces the per-texture rd.texture_create + sampler pair of
+ * PTWorkDispatcher.create_texture_buffers, pt_work_dispatcher.gd:297-347:
+ * RGBA32F level-0 data for slot `slot` of the 512-entry sampler array; rgba
+ * NULL selects the 8x8 filler grid (:350-370). */
+uint64_t ptk_texture_create(ptk_ctx* ctx, int slot, int width, int height, const float* rgba);
+
+/* Replaces compute_list_begin .. compute_list_dispatch .. compute_list_end,
+ * pt_work_dispatcher.gd:470-497.  push128 is the 128-byte push constant block
+ * of _push_constant_byte_array (:771-808); groups are 8x8x1 invocations
+ * (ray_tracer.comp:55).  Asynchronous on the context's stream. */
+int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, int groups_z);
+/* Replaces rd.submit() + rd.sync(), pt_work_dispatcher.gd:494-497. */
+int ptk_sync(ptk_ctx* ctx);
+/* Replaces rd.free_rid, pt_work_dispatcher.gd:457-465. */
+int ptk_free(ptk_ctx* ctx, uint64_t handle);
+
+/* Replaces PTBVHTree.create_bvh (pt_bvh_tree.gd:164-189) ->
+ * PTBVHAxisSort.create_bvh_node_list (pt_bvh_axis_sort.gd:156-229) for one
+ * tree.  aabbs6[i] = object.get_bvh_aabb() as position.xyz,size.xyz and
+ * object_ids[i] = object.get_object_id(), in the order
+ * create_disconnected_node_list visits objects (:62-84: spheres, then
+ * triangles).  mesh_bvhs are handles of trees built earlier for the scene's
+ * PTMeshes (adopted by the new tree), mesh_transforms12 their Transform3D as
+ * basis rows (9) + origin (3), mesh_indices their index in the scene's mesh
+ * list (the transform index). */
+uint64_t ptk_bvh_build(ptk_ctx* ctx, int order, int type, int n_objects, const float* aabbs6,
+                       const int32_t* object_ids, int n_meshes, const uint64_t* mesh_bvhs,
+                       const float* mesh_transforms12, const int32_t* mesh_indices);
+/* Node and object-id counts of a built tree (PTBVHTree.size(), object_ids.size()). */
+int ptk_bvh_sizes(ptk_ctx* ctx, uint64_t bvh, int32_t* n_nodes, int32_t* n_object_ids);
+/* Replaces PTWorkDispatcher._create_bvh_byte_array (index_tree + to_byte_array,
+ * pt_work_dispatcher.gd:723-744) and _create_object_id_byte_array (:747-758):
+ * 32 bytes per node in index_tree order, and the object id table. */
+int ptk_bvh_read(ptk_ctx* ctx, uint64_t bvh, void* node_bytes, int32_t* object_ids);
+
+/* Measurement hooks.  The reference counts box and object tests per invocation
+ * in node_hit_count / object_hit_count (ray_tracer.comp:221-222,672,982) and
+ * can only show them through the BVH-view render mode; these calls expose the
+ * same counters, plus the first segment's hit object_id, as per-pixel buffers.
+ * flags: bit 0 = primary hit id, bit 1 = counters.  With tracing on, a dispatch
+ * also fills the buffers; image output is unchanged. */
+enum { PTK_TRACE_PRIMARY_ID = 1, PTK_TRACE_COUNTERS = 2 };
+enum {
+    PTK_CNT_RAYS = 0, PTK_CNT_BOX_TESTS, PTK_CNT_OBJ_TESTS, PTK_CNT_SPHERE_TESTS, PTK_CNT_TRI_TESTS,
+    PTK_CNT_SOCKETS, PTK_CNT_HIT_SPHERE, PTK_CNT_HIT_PLANE, PTK_CNT_HIT_TRIANGLE, PTK_CNT_MATERIAL_FETCH,
+    PTK_NCOUNTERS
+};
+int ptk_trace_enable(ptk_ctx* ctx, int flags);
+/* which = PTK_TRACE_PRIMARY_ID: width*height int32; PTK_TRACE_COUNTERS: width*height*PTK_NCOUNTERS int32. */
+int ptk_trace_read(ptk_ctx* ctx, int which, void* dst, size_t nbytes);
+/* Duration in milliseconds of the last ptk_dispatch's kernel, from HIP events
+ * recorded on the context's stream around the launch (blocks until it ended). */
+int ptk_last_dispatch_ms(ptk_ctx* ctx, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTK_H */

@@ -1,0 +1,651 @@
+// ptk_api.cpp -- host side of libptk: contexts, buffers, validation, dispatch.
+//
+// Serves the calls the reference's PTWorkDispatcher / PTRenderer make on
+// Godot's RenderingDevice (proprietary_dataclasses/pt_work_dispatcher.gd,
+// pt_renderer.gd); see include/ptk.h for the call-by-call mapping.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ptk_bvh.h"
+#include "ptk_device.h"
+
+namespace {
+
+enum class Kind { Buffer, Image, Texture, Bvh };
+
+struct Object {
+    Kind kind = Kind::Buffer;
+    void* dev = nullptr;
+    size_t nbytes = 0;
+    int set = -1, binding = -1;
+    int width = 0, height = 0, slot = -1;
+    std::vector<uint8_t> shadow;  // host copy of storage buffers (validation, derived tables)
+    std::unique_ptr<PtkBvh> bvh;
+};
+
+struct Slot {
+    uint64_t handle = 0;
+};
+
+}  // namespace
+
+struct ptk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_timing = false;
+    std::string error;
+    std::map<uint64_t, std::unique_ptr<Object>> objects;
+    uint64_t next_handle = 1;
+    std::map<std::pair<int, int>, uint64_t> bound;  // (set, binding) -> buffer handle
+    uint64_t image = 0;
+    std::map<int, uint64_t> texture_slots;
+    // configuration (ptk_configure)
+    int order = 8, refraction_mode = 2, use_emission = 0, early_t_break = 0;
+    int n_proc = 0;
+    int proc_builtin[PTK_MAX_PROC] = {0};
+    // derived state, rebuilt when a bound buffer changes
+    bool dirty = true;
+    int stack_need = 1;
+    int* d_live_planes = nullptr;
+    int n_live_planes = 0;
+    PtkTexDesc* d_textures = nullptr;
+    int n_textures = 0;
+    bool textures_dirty = true;
+    int* d_spill = nullptr;
+    int* d_spill_t = nullptr;
+    size_t spill_ints = 0;
+    // tracing
+    int trace_flags = 0;
+    int* d_trace_primary = nullptr;
+    int* d_trace_counters = nullptr;
+    size_t trace_pixels = 0;
+};
+
+static std::string g_create_error;
+
+static int fail(ptk_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(ctx, PTK_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static Object* find(ptk_ctx* ctx, uint64_t h, Kind kind) {
+    auto it = ctx->objects.find(h);
+    if (it == ctx->objects.end() || it->second->kind != kind) return nullptr;
+    return it->second.get();
+}
+static Object* bound_buffer(ptk_ctx* ctx, int set, int binding) {
+    auto it = ctx->bound.find({set, binding});
+    if (it == ctx->bound.end()) return nullptr;
+    return find(ctx, it->second, Kind::Buffer);
+}
+
+extern "C" {
+
+ptk_ctx* ptk_create(int device_ordinal) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        fail(nullptr, PTK_E_HIP, "no HIP device available (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) {
+        fail(nullptr, PTK_E_INVALID, "device ordinal %d out of range (0..%d)", device_ordinal, n - 1);
+        return nullptr;
+    }
+    if (hipSetDevice(device_ordinal) != hipSuccess) {
+        fail(nullptr, PTK_E_HIP, "hipSetDevice(%d) failed", device_ordinal);
+        return nullptr;
+    }
+    auto* ctx = new ptk_ctx();
+    ctx->device = device_ordinal;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        fail(nullptr, PTK_E_HIP, "stream/event creation failed");
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+static void release(ptk_ctx* ctx, Object* o) {
+    (void)ctx;
+    if (o->dev) (void)hipFree(o->dev);
+    o->dev = nullptr;
+}
+
+void ptk_destroy(ptk_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->objects) release(ctx, kv.second.get());
+    ctx->objects.clear();
+    if (ctx->d_live_planes) (void)hipFree(ctx->d_live_planes);
+    if (ctx->d_textures) (void)hipFree(ctx->d_textures);
+    if (ctx->d_spill) (void)hipFree(ctx->d_spill);
+    if (ctx->d_spill_t) (void)hipFree(ctx->d_spill_t);
+    if (ctx->d_trace_primary) (void)hipFree(ctx->d_trace_primary);
+    if (ctx->d_trace_counters) (void)hipFree(ctx->d_trace_counters);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* ptk_last_error(ptk_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+static bool ends_with(const std::string& s, const char* suffix) {
+    size_t n = strlen(suffix);
+    return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
+}
+
+int ptk_configure(ptk_ctx* ctx, int bvh_order, int refraction_mode, int use_emission, int early_t_break,
+                  const char* const* proc_tex_paths, int n_paths) {
+    if (!ctx) return PTK_E_INVALID;
+    if (bvh_order < 2) return fail(ctx, PTK_E_INVALID, "bvh_order must be >= 2 (got %d)", bvh_order);
+    if (bvh_order > PTK_MAX_WIDTH)
+        return fail(ctx, PTK_E_UNSUPPORTED, "bvh_order %d is wider than the %d the kernels are built for", bvh_order, PTK_MAX_WIDTH);
+    if (refraction_mode < 0 || refraction_mode > 2) return fail(ctx, PTK_E_INVALID, "refraction_mode must be 0, 1 or 2");
+    if (n_paths < 0 || n_paths > PTK_MAX_PROC) return fail(ctx, PTK_E_UNSUPPORTED, "at most %d procedural textures", PTK_MAX_PROC);
+    int builtin[PTK_MAX_PROC] = {0};
+    for (int i = 0; i < n_paths; i++) {
+        std::string p = proc_tex_paths && proc_tex_paths[i] ? proc_tex_paths[i] : "";
+        if (ends_with(p, "checker_board_spatial.comp")) builtin[i] = PTK_PROC_CHECKER_BOARD_SPATIAL;
+        else if (ends_with(p, "checker_board.comp")) builtin[i] = PTK_PROC_CHECKER_BOARD;
+        else return fail(ctx, PTK_E_UNSUPPORTED, "procedural texture '%s' is not one of the built-in functions", p.c_str());
+    }
+    ctx->order = bvh_order;
+    ctx->refraction_mode = refraction_mode;
+    ctx->use_emission = use_emission ? 1 : 0;
+    ctx->early_t_break = early_t_break ? 1 : 0;
+    ctx->n_proc = n_paths;
+    memcpy(ctx->proc_builtin, builtin, sizeof builtin);
+    ctx->dirty = true;
+    return PTK_OK;
+}
+
+uint64_t ptk_buffer_create(ptk_ctx* ctx, int set, int binding, const void* bytes, size_t nbytes) {
+    if (!ctx) return 0;
+    if (nbytes == 0) { fail(ctx, PTK_E_INVALID, "buffer size must be > 0"); return 0; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { fail(ctx, PTK_E_HIP, "hipSetDevice failed"); return 0; }
+    auto o = std::make_unique<Object>();
+    o->kind = Kind::Buffer;
+    o->nbytes = nbytes;
+    o->set = set;
+    o->binding = binding;
+    o->shadow.assign(nbytes, 0);
+    if (bytes) memcpy(o->shadow.data(), bytes, nbytes);
+    size_t alloc = (nbytes + 255) & ~(size_t)255;  // keep 16-byte vector loads of the last record in bounds
+    if (hipMalloc(&o->dev, alloc) != hipSuccess) { fail(ctx, PTK_E_HIP, "hipMalloc(%zu) failed", alloc); return 0; }
+    if (hipMemsetAsync(o->dev, 0, alloc, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(o->dev, o->shadow.data(), nbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipFree(o->dev);
+        fail(ctx, PTK_E_HIP, "upload of %zu bytes failed", nbytes);
+        return 0;
+    }
+    uint64_t h = ctx->next_handle++;
+    ctx->objects[h] = std::move(o);
+    ctx->bound[{set, binding}] = h;
+    ctx->dirty = true;
+    return h;
+}
+
+int ptk_buffer_update(ptk_ctx* ctx, uint64_t buffer, size_t offset, const void* bytes, size_t nbytes) {
+    if (!ctx) return PTK_E_INVALID;
+    Object* o = find(ctx, buffer, Kind::Buffer);
+    if (!o) return fail(ctx, PTK_E_INVALID, "unknown buffer handle %llu", (unsigned long long)buffer);
+    if (!bytes || offset > o->nbytes || nbytes > o->nbytes - offset)
+        return fail(ctx, PTK_E_INVALID, "update of %zu bytes at %zu exceeds buffer of %zu bytes", nbytes, offset, o->nbytes);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    memcpy(o->shadow.data() + offset, bytes, nbytes);
+    // stream-ordered after earlier dispatches; the source is the shadow copy, which outlives the call
+    HIP_TRY(ctx, hipMemcpyAsync((uint8_t*)o->dev + offset, o->shadow.data() + offset, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->dirty = true;
+    return PTK_OK;
+}
+
+int ptk_buffer_read(ptk_ctx* ctx, uint64_t buffer, size_t offset, void* dst, size_t nbytes) {
+    if (!ctx) return PTK_E_INVALID;
+    Object* o = find(ctx, buffer, Kind::Buffer);
+    if (!o) return fail(ctx, PTK_E_INVALID, "unknown buffer handle %llu", (unsigned long long)buffer);
+    if (!dst || offset > o->nbytes || nbytes > o->nbytes - offset) return fail(ctx, PTK_E_INVALID, "read out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, (uint8_t*)o->dev + offset, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTK_OK;
+}
+
+uint64_t ptk_image_create(ptk_ctx* ctx, int width, int height) {
+    if (!ctx) return 0;
+    if (width <= 0 || height <= 0 || width > 65536 || height > 65536) { fail(ctx, PTK_E_INVALID, "bad image size %dx%d", width, height); return 0; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { fail(ctx, PTK_E_HIP, "hipSetDevice failed"); return 0; }
+    auto o = std::make_unique<Object>();
+    o->kind = Kind::Image;
+    o->width = width;
+    o->height = height;
+    o->nbytes = (size_t)width * height * 16;
+    if (hipMalloc(&o->dev, o->nbytes) != hipSuccess) { fail(ctx, PTK_E_HIP, "hipMalloc(%zu) failed", o->nbytes); return 0; }
+    if (hipMemsetAsync(o->dev, 0, o->nbytes, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipFree(o->dev);
+        fail(ctx, PTK_E_HIP, "image clear failed");
+        return 0;
+    }
+    uint64_t h = ctx->next_handle++;
+    ctx->objects[h] = std::move(o);
+    ctx->image = h;
+    return h;
+}
+
+int ptk_image_read(ptk_ctx* ctx, uint64_t image, void* dst, size_t nbytes) {
+    if (!ctx) return PTK_E_INVALID;
+    Object* o = find(ctx, image, Kind::Image);
+    if (!o) return fail(ctx, PTK_E_INVALID, "unknown image handle");
+    if (!dst || nbytes != o->nbytes) return fail(ctx, PTK_E_INVALID, "image read needs exactly %zu bytes", o->nbytes);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, o->dev, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTK_OK;
+}
+
+int ptk_image_update(ptk_ctx* ctx, uint64_t image, const void* src, size_t nbytes) {
+    if (!ctx) return PTK_E_INVALID;
+    Object* o = find(ctx, image, Kind::Image);
+    if (!o) return fail(ctx, PTK_E_INVALID, "unknown image handle");
+    if (!src || nbytes != o->nbytes) return fail(ctx, PTK_E_INVALID, "image update needs exactly %zu bytes", o->nbytes);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(o->dev, src, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTK_OK;
+}
+
+uint64_t ptk_texture_create(ptk_ctx* ctx, int slot, int width, int height, const float* rgba) {
+    if (!ctx) return 0;
+    if (slot < 0 || slot >= 512) { fail(ctx, PTK_E_INVALID, "texture slot %d out of range (0..511)", slot); return 0; }
+    if (rgba && (width <= 0 || height <= 0)) { fail(ctx, PTK_E_INVALID, "bad texture size"); return 0; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { fail(ctx, PTK_E_HIP, "hipSetDevice failed"); return 0; }
+    auto o = std::make_unique<Object>();
+    o->kind = Kind::Texture;
+    o->slot = slot;
+    o->width = rgba ? width : 8;
+    o->height = rgba ? height : 8;
+    if (rgba) {
+        o->nbytes = (size_t)width * height * 16;
+        if (hipMalloc(&o->dev, o->nbytes) != hipSuccess) { fail(ctx, PTK_E_HIP, "hipMalloc failed"); return 0; }
+        if (hipMemcpyAsync(o->dev, rgba, o->nbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            (void)hipFree(o->dev);
+            fail(ctx, PTK_E_HIP, "texture upload failed");
+            return 0;
+        }
+    }
+    uint64_t h = ctx->next_handle++;
+    ctx->objects[h] = std::move(o);
+    ctx->texture_slots[slot] = h;
+    ctx->textures_dirty = true;
+    return h;
+}
+
+int ptk_free(ptk_ctx* ctx, uint64_t handle) {
+    if (!ctx) return PTK_E_INVALID;
+    auto it = ctx->objects.find(handle);
+    if (it == ctx->objects.end()) return fail(ctx, PTK_E_INVALID, "unknown handle %llu", (unsigned long long)handle);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    Object* o = it->second.get();
+    for (auto b = ctx->bound.begin(); b != ctx->bound.end();) {
+        if (b->second == handle) b = ctx->bound.erase(b);
+        else ++b;
+    }
+    for (auto t = ctx->texture_slots.begin(); t != ctx->texture_slots.end();) {
+        if (t->second == handle) { t = ctx->texture_slots.erase(t); ctx->textures_dirty = true; }
+        else ++t;
+    }
+    if (ctx->image == handle) ctx->image = 0;
+    release(ctx, o);
+    ctx->objects.erase(it);
+    ctx->dirty = true;
+    return PTK_OK;
+}
+
+int ptk_sync(ptk_ctx* ctx) {
+    if (!ctx) return PTK_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTK_OK;
+}
+
+}  // extern "C"
+
+// ---- validation of the bound scene ------------------------------------------------
+namespace {
+
+struct NodeView {
+    const uint8_t* p;
+    int n;
+    int node_id(int i) const { int32_t v; memcpy(&v, p + (size_t)i * 32 + 12, 4); return v; }
+    int xform(int i) const { int32_t v; memcpy(&v, p + (size_t)i * 32 + 28, 4); return v; }
+};
+inline int sext(int v, int off, int bits) { return ((int)((uint32_t)v << (32 - off - bits))) >> (32 - bits); }
+
+}  // namespace
+
+// Walks the node buffer exactly as the kernel will and checks every index it
+// can reach, and computes the deepest the traversal stack can get.
+static int validate_scene(ptk_ctx* ctx) {
+    Object* nodes = bound_buffer(ctx, PTK_SET_BVH, 0);
+    Object* ids = bound_buffer(ctx, PTK_SET_BVH, 1);
+    Object* mats = bound_buffer(ctx, PTK_SET_OBJECT, 0);
+    Object* sph = bound_buffer(ctx, PTK_SET_OBJECT, 1);
+    Object* pln = bound_buffer(ctx, PTK_SET_OBJECT, 2);
+    Object* tri = bound_buffer(ctx, PTK_SET_OBJECT, 3);
+    Object* xf = bound_buffer(ctx, PTK_SET_TRANSFORM, 0);
+    if (!nodes || !ids || !mats || !sph || !pln || !tri || !xf)
+        return fail(ctx, PTK_E_STATE, "dispatch needs buffers at (2,0..3), (3,0..1) and (6,0)");
+    if (nodes->nbytes < 32) return fail(ctx, PTK_E_INVALID, "BVH buffer smaller than one node");
+    const int n_nodes = (int)(nodes->nbytes / 32);
+    const int n_ids = (int)(ids->nbytes / 4);
+    const int n_mats = (int)(mats->nbytes / 64);
+    const int n_sph = (int)(sph->nbytes / 32), n_pln = (int)(pln->nbytes / 32), n_tri = (int)(tri->nbytes / 80);
+    const int n_xf = (int)(xf->nbytes / 64);
+    if (n_mats < 1) return fail(ctx, PTK_E_INVALID, "material buffer holds no record");
+
+    auto mat_ok = [&](int m) { return m >= 0 && m < n_mats; };
+    // material indices of every primitive the kernel may resolve
+    for (int i = 0; i < n_sph; i++) { int32_t m; memcpy(&m, sph->shadow.data() + (size_t)i * 32 + 16, 4); if (!mat_ok(m)) return fail(ctx, PTK_E_INVALID, "sphere %d: material index %d out of range", i, m); }
+    for (int i = 0; i < n_pln; i++) { int32_t m; memcpy(&m, pln->shadow.data() + (size_t)i * 32 + 16, 4); if (!mat_ok(m)) return fail(ctx, PTK_E_INVALID, "plane %d: material index %d out of range", i, m); }
+    for (int i = 0; i < n_tri; i++) { int32_t m; memcpy(&m, tri->shadow.data() + (size_t)i * 80 + 64, 4); if (!mat_ok(m)) return fail(ctx, PTK_E_INVALID, "triangle %d: material index %d out of range", i, m); }
+
+    NodeView nv{nodes->shadow.data(), n_nodes};
+    const int32_t* idp = (const int32_t*)ids->shadow.data();
+    // depth-first walk; need(node) = how far the stack can grow above its level
+    // while the subtree of a popped node is processed: all k children are pushed
+    // at once, then each is popped with up to k-1 siblings still below it.
+    std::vector<uint8_t> visited((size_t)n_nodes, 0);
+    std::string walk_error;
+    int walk_code = PTK_OK;
+    struct Walker {
+        const NodeView& nv; const int32_t* idp; std::vector<uint8_t>& visited;
+        int n_nodes, n_ids, n_sph, n_tri, n_xf;
+        std::string& err; int& code;
+        bool bad(int c, const char* fmt, int a = 0, int b = 0, int d = 0) {
+            char buf[256]; snprintf(buf, sizeof buf, fmt, a, b, d); err = buf; code = c; return false;
+        }
+        bool need(int i, int depth, int& out) {
+            if (i < 0 || i >= n_nodes) return bad(PTK_E_INVALID, "BVH references node %d outside the buffer (%d nodes)", i, n_nodes);
+            if (visited[i]) return bad(PTK_E_INVALID, "BVH node %d is reachable twice (not a tree)", i);
+            visited[i] = 1;
+            if (depth > 512) return bad(PTK_E_UNSUPPORTED, "BVH deeper than 512 levels");
+            int id = nv.node_id(i);
+            int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
+            int x = nv.xform(i);
+            if (x >= n_xf) return bad(PTK_E_INVALID, "node %d: transform index %d out of range (%d)", i, x, n_xf);
+            if (idx <= 0) {
+                int base = std::abs(idx) - 1;
+                if (size > 0 && (base < 0 || base + size > n_ids)) return bad(PTK_E_INVALID, "leaf %d: object id slots from %d (count %d) outside the id buffer", i, base, size);
+                for (int k = 0; k < size; k++) {
+                    int oid = idp[base + k];
+                    int type = sext(oid, 24, 8), oi = sext(oid, 0, 24);
+                    if (type == 1 && (oi < 0 || oi >= n_sph)) return bad(PTK_E_INVALID, "leaf %d: sphere index %d out of range", i, oi);
+                    if (type == 3 && (oi < 0 || oi >= n_tri)) return bad(PTK_E_INVALID, "leaf %d: triangle index %d out of range", i, oi);
+                }
+                out = 0;
+                return true;
+            }
+            if (size > PTK_MAX_WIDTH) return bad(PTK_E_UNSUPPORTED, "node %d has %d children; the kernels handle at most %d", i, size, PTK_MAX_WIDTH);
+            if (idx + size > n_nodes) return bad(PTK_E_INVALID, "node %d: children from %d (count %d) outside the buffer", i, idx, size);
+            int best = size;
+            for (int l = 0; l < size; l++) {
+                int c = 0;
+                if (!need(idx + l, depth + 1, c)) return false;
+                best = std::max(best, size - 1 + c);
+            }
+            out = best;
+            return true;
+        }
+    } walker{nv, idp, visited, n_nodes, n_ids, n_sph, n_tri, n_xf, walk_error, walk_code};
+    int result = 0;
+    if (!walker.need(0, 0, result)) return fail(ctx, walk_code, "%s", walk_error.c_str());
+    ctx->stack_need = std::max(1, result + 1);
+    if (ctx->stack_need > 1024)
+        return fail(ctx, PTK_E_UNSUPPORTED, "BVH can need %d stack entries; the reference's traversal stack holds 1024", ctx->stack_need);
+
+    // planes with a non-zero normal, in index order
+    std::vector<int> live;
+    for (int i = 0; i < n_pln; i++) {
+        float nrm[3];
+        memcpy(nrm, pln->shadow.data() + (size_t)i * 32, 12);
+        if (!(nrm[0] == 0.0f && nrm[1] == 0.0f && nrm[2] == 0.0f)) live.push_back(i);
+    }
+    if (ctx->d_live_planes) { (void)hipFree(ctx->d_live_planes); ctx->d_live_planes = nullptr; }
+    ctx->n_live_planes = (int)live.size();
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_live_planes, std::max<size_t>(4, live.size() * 4)));
+    if (!live.empty()) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_live_planes, live.data(), live.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->dirty = false;
+    return PTK_OK;
+}
+
+static int refresh_textures(ptk_ctx* ctx) {
+    int n = 0;
+    for (auto& kv : ctx->texture_slots) n = std::max(n, kv.first + 1);
+    std::vector<PtkTexDesc> table((size_t)std::max(n, 1));
+    for (auto& d : table) { d.rgba = nullptr; d.width = 8; d.height = 8; }
+    for (auto& kv : ctx->texture_slots) {
+        Object* o = find(ctx, kv.second, Kind::Texture);
+        if (!o) continue;
+        table[kv.first].rgba = (const float*)o->dev;
+        table[kv.first].width = o->width;
+        table[kv.first].height = o->height;
+    }
+    if (ctx->d_textures) { (void)hipFree(ctx->d_textures); ctx->d_textures = nullptr; }
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_textures, table.size() * sizeof(PtkTexDesc)));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_textures, table.data(), table.size() * sizeof(PtkTexDesc), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_textures = n;
+    ctx->textures_dirty = false;
+    return PTK_OK;
+}
+
+extern "C" {
+
+int ptk_trace_enable(ptk_ctx* ctx, int flags) {
+    if (!ctx) return PTK_E_INVALID;
+    if (flags & ~(PTK_TRACE_PRIMARY_ID | PTK_TRACE_COUNTERS)) return fail(ctx, PTK_E_INVALID, "unknown trace flags %d", flags);
+    ctx->trace_flags = flags;
+    return PTK_OK;
+}
+
+int ptk_trace_read(ptk_ctx* ctx, int which, void* dst, size_t nbytes) {
+    if (!ctx) return PTK_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int* src = nullptr;
+    size_t need = 0;
+    if (which == PTK_TRACE_PRIMARY_ID) { src = ctx->d_trace_primary; need = ctx->trace_pixels * 4; }
+    else if (which == PTK_TRACE_COUNTERS) { src = ctx->d_trace_counters; need = ctx->trace_pixels * 4 * PTK_NCOUNTERS; }
+    else return fail(ctx, PTK_E_INVALID, "unknown trace buffer %d", which);
+    if (!src) return fail(ctx, PTK_E_STATE, "no traced dispatch has run for buffer %d", which);
+    if (!dst || nbytes != need) return fail(ctx, PTK_E_INVALID, "trace read needs exactly %zu bytes", need);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTK_OK;
+}
+
+int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, int groups_z) {
+    if (!ctx) return PTK_E_INVALID;
+    if (!push128) return fail(ctx, PTK_E_INVALID, "push constants missing");
+    if (groups_x <= 0 || groups_y <= 0 || groups_z != 1 || groups_x > 65535 || groups_y > 65535)
+        return fail(ctx, PTK_E_INVALID, "bad group counts (%d,%d,%d); depth must be 1", groups_x, groups_y, groups_z);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Object* img = find(ctx, ctx->image, Kind::Image);
+    if (!img) return fail(ctx, PTK_E_STATE, "no image bound at (0,0)");
+    if (ctx->dirty) { int r = validate_scene(ctx); if (r != PTK_OK) return r; }
+    if (ctx->textures_dirty) { int r = refresh_textures(ctx); if (r != PTK_OK) return r; }
+
+    PtkParams P;
+    memset(&P, 0, sizeof P);
+    memcpy(&P.push, push128, 128);
+    if (P.push.max_default_depth < 0 || P.push.max_default_depth > 4096 || P.push.max_refraction_bounces < 0 || P.push.max_refraction_bounces > 4096)
+        return fail(ctx, PTK_E_INVALID, "ray depth limits out of range");
+    Object* nodes = bound_buffer(ctx, PTK_SET_BVH, 0);
+    Object* ids = bound_buffer(ctx, PTK_SET_BVH, 1);
+    Object* mats = bound_buffer(ctx, PTK_SET_OBJECT, 0);
+    Object* sph = bound_buffer(ctx, PTK_SET_OBJECT, 1);
+    Object* pln = bound_buffer(ctx, PTK_SET_OBJECT, 2);
+    Object* tri = bound_buffer(ctx, PTK_SET_OBJECT, 3);
+    Object* xf = bound_buffer(ctx, PTK_SET_TRANSFORM, 0);
+    P.nodes = (const float4*)nodes->dev;
+    P.object_ids = (const int*)ids->dev;
+    P.materials = (const float4*)mats->dev;
+    P.spheres = (const float4*)sph->dev;
+    P.planes = (const float4*)pln->dev;
+    P.triangles = (const float4*)tri->dev;
+    P.transforms = (const float4*)xf->dev;
+    P.live_planes = ctx->d_live_planes;
+    P.n_live_planes = ctx->n_live_planes;
+    P.n_spheres = (int)(sph->nbytes / 32);
+    P.n_planes = (int)(pln->nbytes / 32);
+    P.n_triangles = (int)(tri->nbytes / 80);
+    P.image = (float4*)img->dev;
+    P.img_w = img->width;
+    P.img_h = img->height;
+    P.textures = ctx->d_textures;
+    P.n_textures = ctx->n_textures;
+    P.n_proc = ctx->n_proc;
+    memcpy(P.proc_builtin, ctx->proc_builtin, sizeof P.proc_builtin);
+    P.refraction_mode = ctx->refraction_mode;
+    P.use_emission = ctx->use_emission;
+
+    // traversal stack: an LDS window per lane plus a global spill column for deeper entries
+    const int kLdsWindow = 32;
+    const int need = ctx->stack_need;
+    P.lds_cap = std::min(need, kLdsWindow);
+    const size_t lanes = (size_t)groups_x * groups_y * 64;
+    P.spill_stride = lanes;
+    const int spill_entries = need - P.lds_cap;
+    if (spill_entries > 0) {
+        size_t ints = (size_t)spill_entries * lanes;
+        if (ints > ctx->spill_ints) {
+            if (ctx->d_spill) { (void)hipFree(ctx->d_spill); ctx->d_spill = nullptr; }
+            if (ctx->d_spill_t) { (void)hipFree(ctx->d_spill_t); ctx->d_spill_t = nullptr; }
+            ctx->spill_ints = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill, ints * 4));
+            if (ctx->early_t_break) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill_t, ints * 4));
+            ctx->spill_ints = ints;
+        } else if (ctx->early_t_break && !ctx->d_spill_t) {
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_spill_t, ctx->spill_ints * 4));
+        }
+        P.spill = ctx->d_spill;
+        P.spill_t = ctx->d_spill_t;
+    }
+    size_t lds_bytes = (size_t)P.lds_cap * 64 * 4 * (ctx->early_t_break ? 2 : 1);
+
+    const int trace = ctx->trace_flags != 0;
+    if (trace) {
+        size_t pixels = (size_t)img->width * img->height;
+        if (pixels != ctx->trace_pixels) {
+            if (ctx->d_trace_primary) { (void)hipFree(ctx->d_trace_primary); ctx->d_trace_primary = nullptr; }
+            if (ctx->d_trace_counters) { (void)hipFree(ctx->d_trace_counters); ctx->d_trace_counters = nullptr; }
+            ctx->trace_pixels = 0;
+        }
+        if ((ctx->trace_flags & PTK_TRACE_PRIMARY_ID) && !ctx->d_trace_primary) {
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trace_primary, pixels * 4));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_trace_primary, 0xFF, pixels * 4, ctx->stream));
+        }
+        if ((ctx->trace_flags & PTK_TRACE_COUNTERS) && !ctx->d_trace_counters) {
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trace_counters, pixels * 4 * PTK_NCOUNTERS));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_trace_counters, 0, pixels * 4 * PTK_NCOUNTERS, ctx->stream));
+        }
+        ctx->trace_pixels = pixels;
+        P.trace_primary = (ctx->trace_flags & PTK_TRACE_PRIMARY_ID) ? ctx->d_trace_primary : nullptr;
+        P.trace_counters = (ctx->trace_flags & PTK_TRACE_COUNTERS) ? ctx->d_trace_counters : nullptr;
+    }
+
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(ctx, ptk_launch_render(&P, groups_x, groups_y, trace, ctx->early_t_break, lds_bytes, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->have_timing = true;
+    return PTK_OK;
+}
+
+int ptk_last_dispatch_ms(ptk_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return PTK_E_INVALID;
+    if (!ctx->have_timing) return fail(ctx, PTK_E_STATE, "no dispatch has been timed yet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return PTK_OK;
+}
+
+// ---- BVH builder entry points (device work in ptk_bvh.hip) ---------------------------
+uint64_t ptk_bvh_build(ptk_ctx* ctx, int order, int type, int n_objects, const float* aabbs6,
+                       const int32_t* object_ids, int n_meshes, const uint64_t* mesh_bvhs,
+                       const float* mesh_transforms12, const int32_t* mesh_indices) {
+    if (!ctx) return 0;
+    if (hipSetDevice(ctx->device) != hipSuccess) { fail(ctx, PTK_E_HIP, "hipSetDevice failed"); return 0; }
+    if (order < 2 || order > 128) { fail(ctx, PTK_E_INVALID, "BVH order has to be >= 2 (and <= 128)"); return 0; }
+    if (type < PTK_BVH_X_SORTED || type > PTK_BVH_XYZ_SORTED) { fail(ctx, PTK_E_INVALID, "unknown BVH type %d", type); return 0; }
+    if (n_objects < 0 || n_meshes < 0 || n_objects + n_meshes <= 0) { fail(ctx, PTK_E_INVALID, "cannot create bvh without objects or meshes"); return 0; }
+    if (n_objects > 0 && (!aabbs6 || !object_ids)) { fail(ctx, PTK_E_INVALID, "object arrays missing"); return 0; }
+    std::vector<PtkBvh*> subs;
+    for (int m = 0; m < n_meshes; m++) {
+        Object* o = mesh_bvhs ? find(ctx, mesh_bvhs[m], Kind::Bvh) : nullptr;
+        if (!o || !o->bvh) { fail(ctx, PTK_E_INVALID, "mesh %d: unknown BVH handle", m); return 0; }
+        if (o->bvh->adopted) { fail(ctx, PTK_E_INVALID, "mesh %d: BVH already merged into another tree", m); return 0; }
+        subs.push_back(o->bvh.get());
+    }
+    if (n_meshes > 0 && (!mesh_transforms12 || !mesh_indices)) { fail(ctx, PTK_E_INVALID, "mesh arrays missing"); return 0; }
+    std::string err;
+    std::unique_ptr<PtkBvh> bvh = ptk_bvh_build_device(ctx->stream, order, type, n_objects, aabbs6, object_ids, subs,
+                                                      mesh_transforms12, mesh_indices, err);
+    if (!bvh) { fail(ctx, PTK_E_UNSUPPORTED, "bvh build failed: %s", err.c_str()); return 0; }
+    for (PtkBvh* s : subs) s->adopted = true;
+    auto o = std::make_unique<Object>();
+    o->kind = Kind::Bvh;
+    o->bvh = std::move(bvh);
+    uint64_t h = ctx->next_handle++;
+    ctx->objects[h] = std::move(o);
+    return h;
+}
+
+int ptk_bvh_sizes(ptk_ctx* ctx, uint64_t bvh, int32_t* n_nodes, int32_t* n_object_ids) {
+    if (!ctx) return PTK_E_INVALID;
+    Object* o = find(ctx, bvh, Kind::Bvh);
+    if (!o) return fail(ctx, PTK_E_INVALID, "unknown BVH handle");
+    if (n_nodes) *n_nodes = o->bvh->flat_node_count();
+    if (n_object_ids) *n_object_ids = o->bvh->flat_id_count();
+    return PTK_OK;
+}
+
+int ptk_bvh_read(ptk_ctx* ctx, uint64_t bvh, void* node_bytes, int32_t* object_ids) {
+    if (!ctx) return PTK_E_INVALID;
+    Object* o = find(ctx, bvh, Kind::Bvh);
+    if (!o) return fail(ctx, PTK_E_INVALID, "unknown BVH handle");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    if (!o->bvh->flatten(ctx->stream, (uint8_t*)node_bytes, object_ids, err)) return fail(ctx, PTK_E_HIP, "bvh read failed: %s", err.c_str());
+    return PTK_OK;
+}
+
+}  // extern "C"
