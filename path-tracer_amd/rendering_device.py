@@ -1,0 +1,237 @@
+"""ctypes binding of libptk -- the object PTWorkDispatcher.rd points to.
+
+The reference's PTWorkDispatcher talks to Godot's RenderingDevice
+(proprietary_dataclasses/pt_work_dispatcher.gd:146-160,436-497,642-653); this
+class offers the same verbs on top of the C ABI of include/ptk.h.  There is no
+CPU fallback: if the HIP library is missing or no GPU is present, construction
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libptk.so")
+
+PTK_TRACE_PRIMARY_ID = 1
+PTK_TRACE_COUNTERS = 2
+PTK_NCOUNTERS = 10
+COUNTER_NAMES = ["rays", "box_tests", "obj_tests", "sphere_tests", "tri_tests", "sockets",
+                 "hit_sphere", "hit_plane", "hit_triangle", "material_fetch"]
+
+# every symbol include/ptk.h declares
+EXPORTS = [
+    "ptk_create", "ptk_destroy", "ptk_last_error", "ptk_configure", "ptk_buffer_create", "ptk_buffer_update",
+    "ptk_buffer_read", "ptk_image_create", "ptk_image_read", "ptk_image_update", "ptk_texture_create",
+    "ptk_dispatch", "ptk_sync", "ptk_free", "ptk_bvh_build", "ptk_bvh_sizes", "ptk_bvh_read",
+    "ptk_trace_enable", "ptk_trace_read", "ptk_last_dispatch_ms",
+]
+
+_lib = None
+
+
+class PtkError(RuntimeError):
+    pass
+
+
+def load_library() -> C.CDLL:
+    """Loads csrc/libptk.so (built in-tree by __graft_entry__.build or `make`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PtkError(f"HIP library missing: {LIB_PATH} (run `make -C path-tracer_amd/csrc`); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, i32p = C.c_void_p, C.c_uint64, C.POINTER(C.c_int32)
+    lib.ptk_create.restype = vp
+    lib.ptk_create.argtypes = [C.c_int]
+    lib.ptk_destroy.restype = None
+    lib.ptk_destroy.argtypes = [vp]
+    lib.ptk_last_error.restype = C.c_char_p
+    lib.ptk_last_error.argtypes = [vp]
+    lib.ptk_configure.restype = C.c_int
+    lib.ptk_configure.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_int]
+    lib.ptk_buffer_create.restype = u64
+    lib.ptk_buffer_create.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
+    lib.ptk_buffer_update.restype = C.c_int
+    lib.ptk_buffer_update.argtypes = [vp, u64, C.c_size_t, vp, C.c_size_t]
+    lib.ptk_buffer_read.restype = C.c_int
+    lib.ptk_buffer_read.argtypes = [vp, u64, C.c_size_t, vp, C.c_size_t]
+    lib.ptk_image_create.restype = u64
+    lib.ptk_image_create.argtypes = [vp, C.c_int, C.c_int]
+    lib.ptk_image_read.restype = C.c_int
+    lib.ptk_image_read.argtypes = [vp, u64, vp, C.c_size_t]
+    lib.ptk_image_update.restype = C.c_int
+    lib.ptk_image_update.argtypes = [vp, u64, vp, C.c_size_t]
+    lib.ptk_texture_create.restype = u64
+    lib.ptk_texture_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.ptk_dispatch.restype = C.c_int
+    lib.ptk_dispatch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    lib.ptk_sync.restype = C.c_int
+    lib.ptk_sync.argtypes = [vp]
+    lib.ptk_free.restype = C.c_int
+    lib.ptk_free.argtypes = [vp, u64]
+    lib.ptk_bvh_build.restype = u64
+    lib.ptk_bvh_build.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp]
+    lib.ptk_bvh_sizes.restype = C.c_int
+    lib.ptk_bvh_sizes.argtypes = [vp, u64, i32p, i32p]
+    lib.ptk_bvh_read.restype = C.c_int
+    lib.ptk_bvh_read.argtypes = [vp, u64, vp, vp]
+    lib.ptk_trace_enable.restype = C.c_int
+    lib.ptk_trace_enable.argtypes = [vp, C.c_int]
+    lib.ptk_trace_read.restype = C.c_int
+    lib.ptk_trace_read.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.ptk_last_dispatch_ms.restype = C.c_int
+    lib.ptk_last_dispatch_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    _lib = lib
+    return lib
+
+
+def _as_bytes(data) -> bytes:
+    if isinstance(data, (bytes, bytearray, memoryview)):
+        return bytes(data)
+    return np.ascontiguousarray(data).tobytes()
+
+
+class PtkRenderingDevice:
+    """RenderingDevice stand-in; method names follow the RenderingDevice calls the reference makes."""
+
+    def __init__(self, device_ordinal: int = 0):
+        self.lib = load_library()
+        self.ctx = self.lib.ptk_create(device_ordinal)
+        if not self.ctx:
+            raise PtkError("ptk_create failed: " + self.lib.ptk_last_error(None).decode())
+        self._images = {}
+
+    # -- errors ----------------------------------------------------------
+    def _err(self) -> str:
+        return self.lib.ptk_last_error(self.ctx).decode()
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise PtkError(f"{what} failed ({rc}): {self._err()}")
+
+    def close(self):
+        if self.ctx:
+            self.lib.ptk_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- pipeline ("shader") -----------------------------------------------
+    def configure(self, bvh_order=8, refraction_mode=2, use_emission=False, early_t_break=False,
+                  proc_tex_paths: Sequence[str] = ()):
+        arr = (C.c_char_p * max(1, len(proc_tex_paths)))(*[p.encode() for p in proc_tex_paths])
+        self._check(self.lib.ptk_configure(self.ctx, bvh_order, refraction_mode, int(use_emission), int(early_t_break),
+                                           arr, len(proc_tex_paths)), "ptk_configure")
+
+    # -- buffers -----------------------------------------------------------
+    def storage_buffer_create(self, set_index: int, binding: int, data) -> int:
+        b = _as_bytes(data)
+        h = self.lib.ptk_buffer_create(self.ctx, set_index, binding, b, len(b))
+        if not h:
+            raise PtkError("ptk_buffer_create failed: " + self._err())
+        return h
+
+    def buffer_update(self, buffer: int, offset: int, size_bytes: int, data):
+        b = _as_bytes(data)
+        assert len(b) >= size_bytes
+        self._check(self.lib.ptk_buffer_update(self.ctx, buffer, offset, b, size_bytes), "ptk_buffer_update")
+
+    def buffer_get_data(self, buffer: int, offset: int, size_bytes: int) -> bytes:
+        out = C.create_string_buffer(size_bytes)
+        self._check(self.lib.ptk_buffer_read(self.ctx, buffer, offset, out, size_bytes), "ptk_buffer_read")
+        return out.raw
+
+    # -- image / textures -----------------------------------------------------
+    def image_create(self, width: int, height: int) -> int:
+        h = self.lib.ptk_image_create(self.ctx, width, height)
+        if not h:
+            raise PtkError("ptk_image_create failed: " + self._err())
+        self._images[h] = (width, height)
+        return h
+
+    def texture_get_data(self, image: int) -> np.ndarray:
+        w, h = self._images[image]
+        out = np.empty((h, w, 4), dtype=np.float32)
+        self._check(self.lib.ptk_image_read(self.ctx, image, out.ctypes.data, out.nbytes), "ptk_image_read")
+        return out
+
+    def texture_update(self, image: int, data: np.ndarray):
+        d = np.ascontiguousarray(data, dtype=np.float32)
+        self._check(self.lib.ptk_image_update(self.ctx, image, d.ctypes.data, d.nbytes), "ptk_image_update")
+
+    def texture_create(self, slot: int, rgba: Optional[np.ndarray]) -> int:
+        if rgba is None:
+            h = self.lib.ptk_texture_create(self.ctx, slot, 0, 0, None)
+        else:
+            d = np.ascontiguousarray(rgba, dtype=np.float32)
+            h = self.lib.ptk_texture_create(self.ctx, slot, d.shape[1], d.shape[0], d.ctypes.data)
+        if not h:
+            raise PtkError("ptk_texture_create failed: " + self._err())
+        return h
+
+    # -- dispatch -------------------------------------------------------------
+    def compute_list_dispatch(self, push_bytes: bytes, x: int, y: int, z: int = 1):
+        assert len(push_bytes) == 128
+        self._check(self.lib.ptk_dispatch(self.ctx, push_bytes, x, y, z), "ptk_dispatch")
+
+    def sync(self):
+        self._check(self.lib.ptk_sync(self.ctx), "ptk_sync")
+
+    def free_rid(self, handle: int):
+        self._check(self.lib.ptk_free(self.ctx, handle), "ptk_free")
+        self._images.pop(handle, None)
+
+    # -- BVH builder ----------------------------------------------------------
+    def bvh_build(self, order: int, bvh_type: int, aabbs6: np.ndarray, object_ids: np.ndarray,
+                  mesh_bvhs: Sequence[int] = (), mesh_transforms12=None, mesh_indices=None) -> int:
+        a = np.ascontiguousarray(aabbs6, dtype=np.float32).reshape(-1, 6)
+        ids = np.ascontiguousarray(object_ids, dtype=np.int32)
+        nm = len(mesh_bvhs)
+        mh = np.ascontiguousarray(np.array(list(mesh_bvhs), dtype=np.uint64))
+        mt = np.ascontiguousarray(np.array(mesh_transforms12 if nm else [], dtype=np.float32))
+        mi = np.ascontiguousarray(np.array(mesh_indices if nm else [], dtype=np.int32))
+        h = self.lib.ptk_bvh_build(self.ctx, order, bvh_type, a.shape[0], a.ctypes.data, ids.ctypes.data,
+                                   nm, mh.ctypes.data if nm else None, mt.ctypes.data if nm else None,
+                                   mi.ctypes.data if nm else None)
+        if not h:
+            raise PtkError("ptk_bvh_build failed: " + self._err())
+        return h
+
+    def bvh_read(self, bvh: int):
+        nn, ni = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.ptk_bvh_sizes(self.ctx, bvh, C.byref(nn), C.byref(ni)), "ptk_bvh_sizes")
+        nodes = np.empty(nn.value * 32, dtype=np.uint8)
+        ids = np.empty(max(ni.value, 1), dtype=np.int32)
+        self._check(self.lib.ptk_bvh_read(self.ctx, bvh, nodes.ctypes.data, ids.ctypes.data), "ptk_bvh_read")
+        return nodes.tobytes(), ids[: ni.value].copy()
+
+    # -- measurement ------------------------------------------------------------
+    def trace_enable(self, flags: int):
+        self._check(self.lib.ptk_trace_enable(self.ctx, flags), "ptk_trace_enable")
+
+    def trace_read_primary(self, image: int) -> np.ndarray:
+        w, h = self._images[image]
+        out = np.empty((h, w), dtype=np.int32)
+        self._check(self.lib.ptk_trace_read(self.ctx, PTK_TRACE_PRIMARY_ID, out.ctypes.data, out.nbytes), "ptk_trace_read")
+        return out
+
+    def trace_read_counters(self, image: int) -> np.ndarray:
+        w, h = self._images[image]
+        out = np.empty((h, w, PTK_NCOUNTERS), dtype=np.int32)
+        self._check(self.lib.ptk_trace_read(self.ctx, PTK_TRACE_COUNTERS, out.ctypes.data, out.nbytes), "ptk_trace_read")
+        return out
+
+    def last_dispatch_ms(self) -> float:
+        ms = C.c_float(0)
+        self._check(self.lib.ptk_last_dispatch_ms(self.ctx, C.byref(ms)), "ptk_last_dispatch_ms")
+        return float(ms.value)

@@ -270,8 +270,11 @@ class PTMesh:
         return self.transform  # meshes are direct children of the scene root (a plain Node)
 
     def add_object(self, obj: PTObject):
+        """pt_mesh.gd:117-131: the object joins the mesh and, through it, the scene."""
         obj._mesh = self
         self.objects.append(obj)
+        if self.scene is not None:
+            self.scene.add_object(obj)
 
     def to_byte_array(self) -> bytes:
         """global_transform.affine_inverse() as a column-major mat4 with last row (0,0,0,1)."""
@@ -411,11 +414,10 @@ class PTScene:
         self._add_texture(obj.texture)
 
     def add_mesh(self, mesh: PTMesh):
-        """PTMesh._ready + PTScene.add_mesh: the mesh's objects join the scene-wide arrays."""
+        """PTMesh._ready + PTScene.add_mesh (pt_scene.gd:240-275): imported triangles join the
+        scene-wide arrays, then the mesh and its override/default materials are registered."""
         mesh.scene = self
         self.meshes.append(mesh)
-        for obj in mesh.objects:
-            self.add_object(obj)
         ts = mesh.triangle_set
         if ts is not None and len(ts):
             self._tri_sets.append((self.n_triangles, mesh, ts))
