@@ -1,9 +1,942 @@
-// ptk_bvh.hip -- device BVH builder (placeholder until the builder kernels land).
+// ptk_bvh.hip -- BVH builder on the GPU.
+//
+// Reproduces, bit for bit, the tree the reference builds on the CPU:
+//   proprietary_dataclasses/bvh_trees/pt_bvh_axis_sort.gd:62-84,156-229,269-376  (one node per object,
+//       recursive equal-width binning along a fixed or the longest axis)
+//   proprietary_dataclasses/bvh_trees/pt_bvh_tree.gd:457-524,780-791,856-870,910-959 (indexing, ids, node bytes)
+//   proprietary_dataclasses/pt_utils.gd:27-43,71-97 (AABB validity / merge / byte encoding)
+// including the float32 arithmetic of Godot 4.3's AABB / Transform3D and the element order produced by
+// Array.sort_custom (core/templates/sort_array.h: introsort, median-of-3 pivot, threshold 16, heapsort
+// fallback, final insertion sort), whose tie order is observable in the leaves.
+//
+// The recursion is run level by level.  All per-element work of a level is done on the device, one
+// wavefront per list ("call"):
+//   * the list's box is the reference's sequential merge chain (not associative in float32, so it is
+//     evaluated in list order, 64 boxes per coalesced load),
+//   * the sort is an exact emulation of the introsort: every quicksort level is one launch with one wave
+//     per segment; a wave replays the Hoare partition with 64-wide scans from both ends (the swap pairs are
+//     the i-th stop from the left with the i-th stop from the right, exactly as the two-pointer loop meets
+//     them), small segments end in the same stable insertion sort,
+//   * bin indices use the reference's float32-difference / float64-divide, and elements are moved with a
+//     stable per-bin ranking (ballot + popcount), which keeps the list order inside a bin.
+// The host only keeps the tree's topology (which bin became which node) and launches the next level.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
 #include "ptk_bvh.h"
 
-std::unique_ptr<PtkBvh> ptk_bvh_build_device(hipStream_t, int, int, int, const float*, const int32_t*,
-                                             const std::vector<PtkBvh*>&, const float*, const int32_t*,
+namespace {
+
+constexpr int MAX_DEPTH_LIMIT = 32;  // pt_bvh_axis_sort.gd:10
+constexpr int MAXB = 8;              // widest order the device builder bins for
+constexpr int SORT_THRESHOLD = 16;   // SortArray::INTROSORT_THRESHOLD
+
+struct A6 {
+    float p[3], s[3];
+};
+
+#define DEV __device__ __forceinline__
+
+// ---- Godot AABB arithmetic (core/math/aabb.h), float32 ---------------------------------------
+DEV A6 a6_zero() { A6 a; for (int i = 0; i < 3; i++) { a.p[i] = 0.0f; a.s[i] = 0.0f; } return a; }
+DEV float gmin(float a, float b) { return a < b ? a : b; }
+DEV bool a6_valid(const A6& b) {  // pt_utils.gd:27-28
+    bool nonzero = !(b.s[0] == 0.0f && b.s[1] == 0.0f && b.s[2] == 0.0f);
+    bool same = true, fin = true;
+    for (int i = 0; i < 3; i++) {
+        float ap = b.p[i] + gmin(b.s[i], 0.0f);
+        float as = fabsf(b.s[i]);
+        same = same && (ap == b.p[i]) && (as == b.s[i]);
+        fin = fin && (fabsf(b.p[i]) < __builtin_inff()) && (fabsf(b.s[i]) < __builtin_inff());
+    }
+    return nonzero && same && fin;
+}
+DEV A6 a6_merge(const A6& a, const A6& b) {  // AABB::merge_with
+    A6 r;
+    for (int i = 0; i < 3; i++) {
+        float e1 = a.p[i] + a.s[i], e2 = b.p[i] + b.s[i];
+        float mn = a.p[i] < b.p[i] ? a.p[i] : b.p[i];
+        float mx = e1 > e2 ? e1 : e2;
+        r.p[i] = mn;
+        r.s[i] = mx - mn;
+    }
+    return r;
+}
+DEV A6 merge_aabb(const A6& a, const A6& b) {  // pt_utils.gd:34-43
+    bool va = a6_valid(a), vb = a6_valid(b);
+    if (!(va || vb)) return a6_zero();
+    if (!va) return b;
+    if (!vb) return a;
+    return a6_merge(a, b);
+}
+DEV A6 a6_abs(const A6& a) {
+    A6 r;
+    for (int i = 0; i < 3; i++) { r.p[i] = a.p[i] + gmin(a.s[i], 0.0f); r.s[i] = fabsf(a.s[i]); }
+    return r;
+}
+DEV A6 a6_grow(A6 a, float by) {
+    for (int i = 0; i < 3; i++) { a.p[i] -= by; a.s[i] += 2.0f * by; }
+    return a;
+}
+DEV float a6_center(const A6& a, int axis) { return a.p[axis] + a.s[axis] * 0.5f; }
+DEV int a6_longest_axis(const A6& a) {
+    int axis = 0;
+    float m = a.s[0];
+    if (a.s[1] > m) { axis = 1; m = a.s[1]; }
+    if (a.s[2] > m) { axis = 2; }
+    return axis;
+}
+DEV A6 a6_xform(const float* t, const A6& a) {  // Transform3D::xform(AABB); t = basis rows + origin
+    A6 r;
+    for (int i = 0; i < 3; i++) {
+        float lo = t[9 + i], hi = t[9 + i];
+        for (int j = 0; j < 3; j++) {
+            float e = t[i * 3 + j] * a.p[j];
+            float f = t[i * 3 + j] * (a.p[j] + a.s[j]);
+            if (e < f) { lo += e; hi += f; }
+            else { lo += f; hi += e; }
+        }
+        r.p[i] = lo;
+        r.s[i] = hi - lo;
+    }
+    return r;
+}
+DEV A6 a6_load(const float* base, int i) {
+    A6 a;
+    const float* q = base + (size_t)i * 6;
+    a.p[0] = q[0]; a.p[1] = q[1]; a.p[2] = q[2]; a.s[0] = q[3]; a.s[1] = q[4]; a.s[2] = q[5];
+    return a;
+}
+DEV void a6_store(float* base, int i, const A6& a) {
+    float* q = base + (size_t)i * 6;
+    q[0] = a.p[0]; q[1] = a.p[1]; q[2] = a.p[2]; q[3] = a.s[0]; q[4] = a.s[1]; q[5] = a.s[2];
+}
+DEV A6 a6_shfl(const A6& a, int lane) {
+    A6 r;
+    for (int i = 0; i < 3; i++) { r.p[i] = __shfl(a.p[i], lane); r.s[i] = __shfl(a.s[i], lane); }
+    return r;
+}
+
+struct Call {
+    int begin, end;  // range in perm
+};
+struct CallOut {
+    float aabb[6];   // list box after abs().grow(1e-6)
+    int axis;
+    int mesh_count;
+    int counts[MAXB];
+    int error;
+    int pad[3];
+};
+
+// ---- per-call kernels (one wave per call) ------------------------------------------------------
+// list box: sequential merge chain in list order (get_array_aabb, pt_bvh_axis_sort.gd:512-516), then
+// .abs().grow(1e-6) (:277); also counts mesh sockets and picks the axis (:279-280).
+__global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls, const int* perm, const float* in_aabb,
+                                                 const int* in_kind, int type, int fixed_axis, CallOut* out) {
+    int c = blockIdx.x;
+    if (c >= n_calls) return;
+    int lane = threadIdx.x;
+    Call call = calls[c];
+    A6 acc = a6_zero();
+    int meshes = 0;
+    for (int base = call.begin; base < call.end; base += 64) {
+        int i = base + lane;
+        bool in = i < call.end;
+        A6 mine = a6_zero();
+        int kind = 0;
+        if (in) { int id = perm[i]; mine = a6_load(in_aabb, id); kind = in_kind[id]; }
+        meshes += __popcll(__ballot(in && kind == 1));
+        int cnt = min(64, call.end - base);
+        for (int j = 0; j < cnt; j++) {
+            A6 b = a6_shfl(mine, j);
+            acc = merge_aabb(acc, b);
+        }
+    }
+    if (lane == 0) {
+        A6 g = a6_grow(a6_abs(acc), 0.000001f);
+        CallOut o;
+        for (int i = 0; i < 3; i++) { o.aabb[i] = g.p[i]; o.aabb[3 + i] = g.s[i]; }
+        o.axis = (type == 4) ? a6_longest_axis(g) : fixed_axis;
+        o.mesh_count = meshes;
+        for (int b = 0; b < MAXB; b++) o.counts[b] = 0;
+        o.error = 0;
+        o.pad[0] = o.pad[1] = o.pad[2] = 0;
+        out[c] = o;
+    }
+}
+
+// sort key of every element of a call: centre of its box on the call's axis (pt_bvh_axis_sort.gd:180-181)
+__global__ __launch_bounds__(64) void k_keys(const Call* calls, int n_calls, const int* perm, const float* in_aabb,
+                                             const CallOut* co, float* keys) {
+    int c = blockIdx.x;
+    if (c >= n_calls) return;
+    Call call = calls[c];
+    int axis = co[c].axis;
+    for (int i = call.begin + threadIdx.x; i < call.end; i += 64) {
+        A6 a = a6_load(in_aabb, perm[i]);
+        keys[i] = a6_center(a, axis);
+    }
+}
+
+// bin index of every element (pt_bvh_axis_sort.gd:304-309) + per-bin counts
+__global__ __launch_bounds__(64) void k_bins(const Call* calls, int n_calls, const int* perm, const float* in_aabb,
+                                             const int* seg_count, CallOut* co, unsigned char* bins) {
+    int c = blockIdx.x;
+    if (c >= n_calls) return;
+    int lane = threadIdx.x;
+    Call call = calls[c];
+    CallOut o = co[c];
+    int axis = o.axis;
+    int segs = seg_count[c];
+    // (size / segment_count)[axis]: float32 divide, widened to double
+    double segment = (double)(o.aabb[3 + axis] / (float)segs);
+    int counts[MAXB];
+    for (int b = 0; b < MAXB; b++) counts[b] = 0;
+    int err = 0;
+    for (int base = call.begin; base < call.end; base += 64) {
+        int i = base + lane;
+        bool in = i < call.end;
+        int bin = -1;
+        if (in) {
+            A6 a = a6_load(in_aabb, perm[i]);
+            float rel = a6_center(a, axis) - o.aabb[axis];
+            double q = floor((double)rel / segment);
+            if (!(q >= 0.0 && q < (double)segs)) { err = 1; q = 0.0; }
+            bin = (int)q;
+            bins[i] = (unsigned char)bin;
+        }
+        for (int b = 0; b < MAXB; b++) counts[b] += __popcll(__ballot(in && bin == b));
+    }
+    err = __any(err);
+    if (lane == 0) {
+        for (int b = 0; b < MAXB; b++) co[c].counts[b] = counts[b];
+        co[c].error = err;
+    }
+}
+
+// stable partition of a call's range by bin (bins keep list order); two passes through tmp
+__global__ __launch_bounds__(64) void k_partition(const Call* calls, int n_calls, const unsigned char* do_move, int* perm,
+                                                  int* tmp, const CallOut* co, const unsigned char* bins) {
+    int c = blockIdx.x;
+    if (c >= n_calls || !do_move[c]) return;
+    int lane = threadIdx.x;
+    Call call = calls[c];
+    int offs[MAXB];
+    int run = call.begin;
+    for (int b = 0; b < MAXB; b++) { offs[b] = run; run += co[c].counts[b]; }
+    unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int base = call.begin; base < call.end; base += 64) {
+        int i = base + lane;
+        bool in = i < call.end;
+        int bin = in ? (int)bins[i] : -1;
+        int v = in ? perm[i] : 0;
+        for (int b = 0; b < MAXB; b++) {
+            unsigned long long m = __ballot(in && bin == b);
+            if (in && bin == b) tmp[offs[b] + __popcll(m & lt)] = v;
+            offs[b] += __popcll(m);
+        }
+    }
+    __threadfence_block();
+    for (int i = call.begin + lane; i < call.end; i += 64) perm[i] = tmp[i];
+}
+
+// ---- exact emulation of Godot's SortArray on (key descending, payload) ------------------------------
+struct Seg {
+    int first, last, depth;
+};
+DEV bool cmp_less(float a, float b) { return a > b; }  // comparator of pt_bvh_axis_sort.gd:180-181
+
+DEV float median_of_3(float a, float b, float c) {
+    if (cmp_less(a, b)) {
+        if (cmp_less(b, c)) return b;
+        else if (cmp_less(a, c)) return c;
+        else return a;
+    } else if (cmp_less(a, c)) return a;
+    else if (cmp_less(b, c)) return c;
+    else return b;
+}
+
+// heapsort fallback (SortArray::partial_sort with middle == last), run by one lane
+DEV void heap_adjust(float* k, int* v, int first, int hole, int len, float kv, int vv) {
+    int top = hole;
+    int second = 2 * hole + 2;
+    while (second < len) {
+        if (cmp_less(k[first + second], k[first + (second - 1)])) second--;
+        k[first + hole] = k[first + second]; v[first + hole] = v[first + second];
+        hole = second;
+        second = 2 * (second + 1);
+    }
+    if (second == len) {
+        k[first + hole] = k[first + (second - 1)]; v[first + hole] = v[first + (second - 1)];
+        hole = second - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && cmp_less(k[first + parent], kv)) {
+        k[first + hole] = k[first + parent]; v[first + hole] = v[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    k[first + hole] = kv; v[first + hole] = vv;
+}
+DEV void heap_sort(float* k, int* v, int first, int last) {
+    int len = last - first;
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        for (;;) {
+            heap_adjust(k, v, first, parent, len, k[first + parent], v[first + parent]);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    int middle = last;
+    while (middle - first > 1) {
+        float kv = k[middle - 1]; int vv = v[middle - 1];
+        k[middle - 1] = k[first]; v[middle - 1] = v[first];
+        heap_adjust(k, v, first, 0, (middle - 1) - first, kv, vv);
+        middle--;
+    }
+}
+
+// One quicksort level: one wave per segment replays SortArray::partitioner and queues the two parts.
+__global__ __launch_bounds__(64) void k_sort_level(const Seg* segs, int n_segs, float* keys, int* vals, Seg* next,
+                                                   int* next_count, Seg* finals, int* final_count) {
+    int s = blockIdx.x;
+    if (s >= n_segs) return;
+    const int lane = threadIdx.x;
+    Seg seg = segs[s];
+    const int first = seg.first, last = seg.last;
+    if (seg.depth == 0) {
+        if (lane == 0) heap_sort(keys, vals, first, last);
+        return;  // already fully sorted; the final insertion pass leaves it unchanged
+    }
+    const float P = median_of_3(keys[first], keys[first + (last - first) / 2], keys[last - 1]);
+
+    unsigned long long ML = 0, MR = 0;  // pending stops of the loaded chunks
+    int bl = first, br = last - 1;      // chunk bases: left chunk covers bl+lane, right chunk br-lane
+    int lf = first, rt = last;          // next unscanned positions (left inclusive, right exclusive)
+    float kL = 0.0f, kR = 0.0f;
+    int vL = 0, vR = 0;
+    int Rk = last;                      // position of the last swapped right element (R_0 = last)
+    int cut;
+    for (;;) {
+        while (ML == 0 && lf < last) {  // next 64 from the left: stops are elements with !(a < pivot)
+            bl = lf;
+            int i = bl + lane;
+            bool in = i < last;
+            if (in) { kL = keys[i]; vL = vals[i]; }
+            ML = __ballot(in && !cmp_less(kL, P));
+            lf += 64;
+        }
+        while (MR == 0 && rt > first) {  // next 64 from the right: stops are elements with !(pivot < a)
+            br = rt - 1;
+            int j = br - lane;
+            bool in = j >= first;
+            if (in) { kR = keys[j]; vR = vals[j]; }
+            MR = __ballot(in && !cmp_less(P, kR));
+            rt -= 64;
+        }
+        if (ML == 0) { cut = Rk; break; }
+        const int bitL = __builtin_ctzll(ML);
+        const int L = bl + bitL;
+        if (MR == 0) { cut = min(L, Rk); break; }
+        const int bitR = __builtin_ctzll(MR);
+        const int R = br - bitR;
+        if (L < R) {
+            float ka = __shfl(kL, bitL), kb = __shfl(kR, bitR);
+            int va = __shfl(vL, bitL), vb = __shfl(vR, bitR);
+            if (lane == 0) { keys[L] = kb; vals[L] = vb; keys[R] = ka; vals[R] = va; }
+            ML &= ML - 1;
+            MR &= MR - 1;
+            Rk = R;
+        } else {
+            cut = min(L, Rk);
+            break;
+        }
+    }
+    if (lane == 0) {
+        // introsort(cut, last, depth-1); last = cut (same depth budget)
+        Seg a = {cut, last, seg.depth - 1}, b = {first, cut, seg.depth - 1};
+        Seg parts[2] = {a, b};
+        for (int q = 0; q < 2; q++) {
+            int len = parts[q].last - parts[q].first;
+            if (len > SORT_THRESHOLD) next[atomicAdd(next_count, 1)] = parts[q];
+            else if (len > 1) finals[atomicAdd(final_count, 1)] = parts[q];
+        }
+    }
+}
+
+// final_insertion_sort restricted to one finished segment (elements never cross partition cuts): stable
+__global__ void k_sort_final(const Seg* finals, int n, float* keys, int* vals) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    Seg seg = finals[s];
+    for (int i = seg.first + 1; i < seg.last; i++) {
+        float kv = keys[i];
+        int vv = vals[i];
+        int j = i;
+        while (j > seg.first && cmp_less(kv, keys[j - 1])) {
+            keys[j] = keys[j - 1]; vals[j] = vals[j - 1];
+            j--;
+        }
+        keys[j] = kv; vals[j] = vv;
+    }
+}
+
+// ---- tree finishing ---------------------------------------------------------------------------------
+// leaf boxes: merge chain over the leaf's objects in order (BVHNode.set_aabb, pt_bvh_tree.gd:862-865)
+__global__ void k_leaf_boxes(int n, const int* leaf_node, const int* obj_begin, const int* obj_count, const int* perm,
+                             const float* in_aabb, float* node_aabb) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    A6 acc = a6_zero();
+    int b = obj_begin[t], cnt = obj_count[t];
+    for (int k = 0; k < cnt; k++) acc = merge_aabb(acc, a6_load(in_aabb, perm[b + k]));
+    a6_store(node_aabb, leaf_node[t], acc);
+}
+// socket boxes: mesh.transform * mesh_root.aabb (pt_bvh_tree.gd:858-860)
+__global__ void k_socket_box(const float* transform12, const float* mesh_root_aabb, float* dst6) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float t[12];
+    for (int i = 0; i < 12; i++) t[i] = transform12[i];
+    A6 a = a6_load(mesh_root_aabb, 0);
+    A6 r = a6_xform(t, a);
+    a6_store(dst6, 0, r);
+}
+// inner boxes of one tree level: merge chain over the children in order (:867-870)
+__global__ void k_inner_boxes(int n, const int* nodes, const int* child_begin, const int* child_count, const int* children,
+                              float* node_aabb) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    A6 acc = a6_zero();
+    int b = child_begin[t], cnt = child_count[t];
+    for (int k = 0; k < cnt; k++) acc = merge_aabb(acc, a6_load(node_aabb, children[b + k]));
+    a6_store(node_aabb, nodes[t], acc);
+}
+__global__ void k_copy_box(const float* src, int si, float* dst, int di) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) a6_store(dst, di, a6_load(src, si));
+}
+// node bytes (pt_utils.gd:71-97 + pt_bvh_tree.gd:910-959)
+__global__ void k_encode(int n, const int* box_index, const int* node_id, const int* xform, const unsigned char* is_empty_root,
+                         const float* boxes, float* out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float* o = out + (size_t)t * 8;
+    if (is_empty_root[t]) { for (int i = 0; i < 8; i++) o[i] = 0.0f; return; }
+    A6 raw = a6_load(boxes, box_index[t]);
+    A6 a = a6_abs(raw);
+    bool zero = raw.s[0] == 0.0f && raw.s[1] == 0.0f && raw.s[2] == 0.0f;
+    float pad = zero ? 0.0f : 1e-6f;
+    o[0] = a.p[0] - pad; o[1] = a.p[1] - pad; o[2] = a.p[2] - pad;
+    o[3] = __int_as_float(node_id[t]);
+    o[4] = (a.p[0] + a.s[0]) + pad; o[5] = (a.p[1] + a.s[1]) + pad; o[6] = (a.p[2] + a.s[2]) + pad;
+    o[7] = __int_as_float(xform[t]);
+}
+// A node created for one object holds merge_aabb(AABB(), object box): an invalid (e.g. zero-size) object
+// box leaves the node with the zero box (pt_bvh_axis_sort.gd:70-73 + pt_bvh_tree.gd:862-865).
+__global__ void k_canonical_boxes(int n, float* in_aabb) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    A6 a = a6_load(in_aabb, t);
+    a6_store(in_aabb, t, merge_aabb(a6_zero(), a));
+}
+__global__ void k_iota(int n, int* p) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) p[t] = t;
+}
+__global__ void k_gather_ids(int n, const int* perm, const int* in_ref, int* out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = in_ref[perm[t]];
+}
+
+// ---- host side -------------------------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool alloc(size_t count) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        n = count;
+        return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)) == hipSuccess;
+    }
+};
+
+enum { N_INNER = 0, N_LEAF = 1, N_SOCKET = 2 };
+
+struct HNode {
+    int kind = N_INNER;
+    std::vector<int> children;  // inner / socket (socket: the mesh root is not a local node)
+    int obj_begin = 0, obj_count = 0;  // leaf: range of perm
+    int mesh_slot = -1;                // socket
+    bool recursive = false;            // created for a bin that was split further
+    bool terminal_mesh = false;        // terminal bin of a list that contains sockets
+};
+
+struct BvhImpl : PtkBvh {
+    int order = 8, type = 1;
+    int n_objects = 0, n_in = 0;
+    std::vector<HNode> nodes;          // node 0 = root
+    std::vector<int> leaf_order;       // index_node order of this tree's own leaves
+    std::vector<BvhImpl*> meshes;      // adopted sub-trees (owned elsewhere, kept alive by their handles)
+    std::vector<int> mesh_index;       // transform index of each mesh
+    DevBuf<float> in_aabb;             // n_in boxes
+    DevBuf<int> in_kind, in_ref;       // 0 object / 1 socket; object id
+    DevBuf<int> perm;                  // final element order
+    DevBuf<float> node_aabb;           // one box per node
+    int own_object_count = 0;
+
+    int own_nodes() const { return (int)nodes.size(); }
+    int flat_node_count() const override {
+        int n = own_nodes();
+        for (auto* m : meshes) n += m->flat_node_count();
+        return n;
+    }
+    int flat_id_count() const override {
+        int n = own_object_count;
+        for (auto* m : meshes) n += m->flat_id_count();
+        return n;
+    }
+    bool flatten(hipStream_t stream, uint8_t* node_bytes, int32_t* object_ids, std::string& err) override;
+};
+
+#define CK(expr)                                                                   \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return false; } \
+    } while (0)
+
+// exact sort of every given range of (keys, vals): level-synchronous introsort emulation
+bool device_sort(hipStream_t st, const std::vector<Seg>& ranges, float* keys, int* vals, int n_total, std::string& err) {
+    std::vector<Seg> cur;
+    std::vector<Seg> finals_host;
+    for (const Seg& r : ranges) {
+        int len = r.last - r.first;
+        if (len > SORT_THRESHOLD) cur.push_back(r);
+        else if (len > 1) finals_host.push_back(r);
+    }
+    size_t cap = (size_t)n_total / 2 + ranges.size() + 16;
+    DevBuf<Seg> qa, qb, finals;
+    DevBuf<int> counters;
+    if (!qa.alloc(cap) || !qb.alloc(cap) || !finals.alloc(cap) || !counters.alloc(2)) { err = "sort queues: out of memory"; return false; }
+    int n_final = (int)finals_host.size();
+    if (n_final) CK(hipMemcpyAsync(finals.p, finals_host.data(), sizeof(Seg) * n_final, hipMemcpyHostToDevice, st));
+    int n_cur = (int)cur.size();
+    if (n_cur) CK(hipMemcpyAsync(qa.p, cur.data(), sizeof(Seg) * n_cur, hipMemcpyHostToDevice, st));
+    Seg* in = qa.p;
+    Seg* out = qb.p;
+    int guard = 0;
+    while (n_cur > 0) {
+        int h[2] = {0, n_final};
+        CK(hipMemcpyAsync(counters.p, h, sizeof h, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_sort_level, dim3(n_cur), dim3(64), 0, st, in, n_cur, keys, vals, out, counters.p, finals.p, counters.p + 1);
+        CK(hipGetLastError());
+        CK(hipMemcpyAsync(h, counters.p, sizeof h, hipMemcpyDeviceToHost, st));
+        CK(hipStreamSynchronize(st));
+        n_cur = h[0];
+        n_final = h[1];
+        std::swap(in, out);
+        if (++guard > 200) { err = "sort did not terminate"; return false; }
+    }
+    if (n_final > 0) {
+        hipLaunchKernelGGL(k_sort_final, dim3((n_final + 63) / 64), dim3(64), 0, st, finals.p, n_final, keys, vals);
+        CK(hipGetLastError());
+    }
+    CK(hipStreamSynchronize(st));
+    return true;
+}
+
+int bitlog(int n) { int k = 0; for (; n != 1; n >>= 1) ++k; return k; }
+
+struct PendingCall {
+    int begin, end;
+    int parent;  // host node that receives the new nodes as children
+};
+
+bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* object_ids,
+                const float* mesh_transforms12, std::string& err) {
+    const int N = T.n_objects, M = (int)T.meshes.size(), n_in = N + M;
+    T.n_in = n_in;
+    if (!T.in_aabb.alloc((size_t)n_in * 6) || !T.in_kind.alloc(n_in) || !T.in_ref.alloc(n_in) || !T.perm.alloc(n_in)) { err = "out of device memory"; return false; }
+    std::vector<int> kind(n_in, 0), ref(n_in, -1);
+    for (int i = 0; i < N; i++) ref[i] = object_ids[i];
+    for (int m = 0; m < M; m++) { kind[N + m] = 1; ref[N + m] = m; }
+    if (N) CK(hipMemcpyAsync(T.in_aabb.p, aabbs6, sizeof(float) * 6 * N, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(T.in_kind.p, kind.data(), sizeof(int) * n_in, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(T.in_ref.p, ref.data(), sizeof(int) * n_in, hipMemcpyHostToDevice, st));
+    DevBuf<float> xf;
+    if (M) {
+        if (!xf.alloc((size_t)M * 12)) { err = "out of device memory"; return false; }
+        CK(hipMemcpyAsync(xf.p, mesh_transforms12, sizeof(float) * 12 * M, hipMemcpyHostToDevice, st));
+        for (int m = 0; m < M; m++) {
+            hipLaunchKernelGGL(k_socket_box, dim3(1), dim3(1), 0, st, xf.p + (size_t)m * 12, T.meshes[m]->node_aabb.p, T.in_aabb.p + (size_t)(N + m) * 6);
+            CK(hipGetLastError());
+        }
+    }
+    if (N) {
+        hipLaunchKernelGGL(k_canonical_boxes, dim3((N + 255) / 256), dim3(256), 0, st, N, T.in_aabb.p);
+        CK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_iota, dim3((n_in + 255) / 256), dim3(256), 0, st, n_in, T.perm.p);
+    CK(hipGetLastError());
+
+    DevBuf<float> keys;
+    DevBuf<int> tmp;
+    DevBuf<unsigned char> bins;
+    if (!keys.alloc(n_in) || !tmp.alloc(n_in) || !bins.alloc(n_in)) { err = "out of device memory"; return false; }
+
+    const int fixed_axis = (T.type == 2) ? 1 : (T.type == 3) ? 2 : 0;
+    T.nodes.clear();
+    T.nodes.emplace_back();  // root (inner)
+    std::vector<PendingCall> calls = {{0, n_in, 0}};
+    DevBuf<Call> d_calls;
+    DevBuf<CallOut> d_out;
+    DevBuf<int> d_segcount;
+    DevBuf<unsigned char> d_move;
+
+    // fixed-axis trees sort the whole list once before the recursion (pt_bvh_axis_sort.gd:193-194)
+    if (T.type != 4) {
+        Call c0 = {0, n_in};
+        CallOut o0;
+        memset(&o0, 0, sizeof o0);
+        o0.axis = fixed_axis;
+        if (!d_calls.alloc(1) || !d_out.alloc(1)) { err = "out of device memory"; return false; }
+        CK(hipMemcpyAsync(d_calls.p, &c0, sizeof c0, hipMemcpyHostToDevice, st));
+        CK(hipMemcpyAsync(d_out.p, &o0, sizeof o0, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_keys, dim3(1), dim3(64), 0, st, d_calls.p, 1, T.perm.p, T.in_aabb.p, d_out.p, keys.p);
+        CK(hipGetLastError());
+        std::vector<Seg> r = {{0, n_in, n_in > 1 ? bitlog(n_in) * 2 : 0}};
+        if (!device_sort(st, r, keys.p, T.perm.p, n_in, err)) return false;
+    }
+
+    for (int depth = 0; !calls.empty(); depth++) {
+        if (depth >= MAX_DEPTH_LIMIT + 5) { err = "too much depth (reference assert)"; return false; }
+        const int nc = (int)calls.size();
+        std::vector<Call> hc(nc);
+        for (int i = 0; i < nc; i++) hc[i] = {calls[i].begin, calls[i].end};
+        if (!d_calls.alloc(nc) || !d_out.alloc(nc) || !d_segcount.alloc(nc) || !d_move.alloc(nc)) { err = "out of device memory"; return false; }
+        CK(hipMemcpyAsync(d_calls.p, hc.data(), sizeof(Call) * nc, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_list_box, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, T.in_kind.p, T.type, fixed_axis, d_out.p);
+        CK(hipGetLastError());
+        std::vector<CallOut> ho(nc);
+        if (T.type == 4) {
+            hipLaunchKernelGGL(k_keys, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, d_out.p, keys.p);
+            CK(hipGetLastError());
+            std::vector<Seg> r(nc);
+            for (int i = 0; i < nc; i++) {
+                int len = hc[i].end - hc[i].begin;
+                r[i] = {hc[i].begin, hc[i].end, len > 1 ? bitlog(len) * 2 : 0};
+            }
+            if (!device_sort(st, r, keys.p, T.perm.p, n_in, err)) return false;
+        }
+        CK(hipMemcpyAsync(ho.data(), d_out.p, sizeof(CallOut) * nc, hipMemcpyDeviceToHost, st));
+        CK(hipStreamSynchronize(st));
+        // segment_count (pt_bvh_axis_sort.gd:276,288-296)
+        std::vector<int> segc(nc, T.order);
+        for (int i = 0; i < nc; i++) {
+            if (depth >= MAX_DEPTH_LIMIT) {
+                int mc = ho[i].mesh_count;
+                if (mc >= T.order) { /* warning only */ }
+                else if (mc > 0) segc[i] = T.order - mc;
+            }
+        }
+        CK(hipMemcpyAsync(d_segcount.p, segc.data(), sizeof(int) * nc, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_bins, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, d_segcount.p, d_out.p, bins.p);
+        CK(hipGetLastError());
+        CK(hipMemcpyAsync(ho.data(), d_out.p, sizeof(CallOut) * nc, hipMemcpyDeviceToHost, st));
+        CK(hipStreamSynchronize(st));
+        // which calls move elements: those with more than one non-empty bin (:314-325)
+        std::vector<unsigned char> mv(nc, 0);
+        for (int i = 0; i < nc; i++) {
+            if (ho[i].error) { err = "a node's centre falls outside its list's bins (reference assert 0 <= index < segment_count)"; return false; }
+            int nonempty = 0;
+            for (int b = 0; b < segc[i]; b++) nonempty += ho[i].counts[b] > 0;
+            mv[i] = nonempty > 1;
+        }
+        CK(hipMemcpyAsync(d_move.p, mv.data(), nc, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_partition, dim3(nc), dim3(64), 0, st, d_calls.p, nc, d_move.p, T.perm.p, tmp.p, d_out.p, bins.p);
+        CK(hipGetLastError());
+
+        // host: one new node per non-empty bin, in bin order (:327-371)
+        std::vector<PendingCall> next;
+        std::vector<int> fix_begin, fix_end;  // terminal bins of lists with sockets: need objects/sockets split
+        for (int i = 0; i < nc; i++) {
+            const int n = calls[i].end - calls[i].begin;
+            std::vector<std::pair<int, int>> ranges;  // [begin,end) of each bin list, in order
+            if (mv[i]) {
+                int run = calls[i].begin;
+                for (int b = 0; b < segc[i]; b++) { ranges.push_back({run, run + ho[i].counts[b]}); run += ho[i].counts[b]; }
+            } else {
+                int half = n / 2;  // a single occupied bin is cut in halves
+                ranges.push_back({calls[i].begin, calls[i].begin + half});
+                ranges.push_back({calls[i].begin + half, calls[i].end});
+            }
+            const int mesh_count = ho[i].mesh_count;
+            for (auto& r : ranges) {
+                int cnt = r.second - r.first;
+                if (cnt == 0) continue;
+                int id = (int)T.nodes.size();
+                T.nodes.emplace_back();
+                T.nodes[calls[i].parent].children.push_back(id);
+                if (cnt > T.order && depth < MAX_DEPTH_LIMIT) {
+                    T.nodes[id].recursive = true;
+                    next.push_back({r.first, r.second, id});
+                } else if (mesh_count == 0) {
+                    T.nodes[id].kind = N_LEAF;
+                    T.nodes[id].obj_begin = r.first;
+                    T.nodes[id].obj_count = cnt;
+                } else {
+                    T.nodes[id].terminal_mesh = true;
+                    T.nodes[id].obj_begin = r.first;  // resolved below
+                    T.nodes[id].obj_count = cnt;
+                }
+            }
+        }
+        calls.swap(next);
+    }
+    CK(hipStreamSynchronize(st));
+
+    // terminal bins of lists that contain sockets: sockets become children in list order, the objects
+    // go to one leaf child that is added last (pt_bvh_axis_sort.gd:349-369).  These lists are tiny.
+    {
+        bool any = false;
+        for (auto& nd : T.nodes) any = any || nd.terminal_mesh;
+        if (any) {
+            std::vector<int> hperm(n_in);
+            CK(hipMemcpy(hperm.data(), T.perm.p, sizeof(int) * n_in, hipMemcpyDeviceToHost));
+            const int n_nodes0 = (int)T.nodes.size();
+            for (int id = 0; id < n_nodes0; id++) {
+                if (!T.nodes[id].terminal_mesh) continue;
+                int b = T.nodes[id].obj_begin, cnt = T.nodes[id].obj_count;
+                std::vector<int> objs, socks;
+                for (int k = 0; k < cnt; k++) (kind[hperm[b + k]] == 1 ? socks : objs).push_back(hperm[b + k]);
+                for (size_t k = 0; k < objs.size(); k++) hperm[b + k] = objs[k];
+                for (size_t k = 0; k < socks.size(); k++) hperm[b + objs.size() + k] = socks[k];
+                if ((int)socks.size() + (objs.empty() ? 0 : 1) > T.order) { err = "a node would hold more children than the order allows (reference assert)"; return false; }
+                for (int s : socks) {
+                    int sid = (int)T.nodes.size();
+                    T.nodes.emplace_back();
+                    T.nodes[sid].kind = N_SOCKET;
+                    T.nodes[sid].mesh_slot = s - N;
+                    T.nodes[id].children.push_back(sid);
+                }
+                if (!objs.empty()) {
+                    int lid = (int)T.nodes.size();
+                    T.nodes.emplace_back();
+                    T.nodes[lid].kind = N_LEAF;
+                    T.nodes[lid].obj_begin = b;
+                    T.nodes[lid].obj_count = (int)objs.size();
+                    T.nodes[id].children.push_back(lid);
+                }
+                T.nodes[id].obj_count = 0;
+            }
+            CK(hipMemcpy(T.perm.p, hperm.data(), sizeof(int) * n_in, hipMemcpyHostToDevice));
+        }
+    }
+    if ((int)T.nodes[0].children.size() > T.order) { err = "root would hold more children than the order allows"; return false; }
+
+    // leaf order = order of index_node calls (pt_bvh_axis_sort.gd:364-374): inside one call, split bins
+    // contribute their whole subtree first and socket-list leaves immediately; plain leaves come last.
+    T.leaf_order.clear();
+    {
+        struct Frame { int node; size_t child; };
+        std::vector<Frame> stack = {{0, 0}};
+        while (!stack.empty()) {
+            Frame& f = stack.back();
+            HNode& nd = T.nodes[f.node];
+            if (f.child < nd.children.size()) {
+                int c = nd.children[f.child++];
+                if (T.nodes[c].recursive) stack.push_back({c, 0});
+                else if (T.nodes[c].terminal_mesh) {
+                    for (int g : T.nodes[c].children) if (T.nodes[g].kind == N_LEAF) T.leaf_order.push_back(g);
+                }
+                continue;
+            }
+            for (int c : nd.children) if (T.nodes[c].kind == N_LEAF) T.leaf_order.push_back(c);
+            stack.pop_back();
+        }
+    }
+    T.own_object_count = 0;
+    for (int l : T.leaf_order) T.own_object_count += T.nodes[l].obj_count;
+
+    // boxes: leaves, sockets, then inner nodes bottom-up
+    const int nn = (int)T.nodes.size();
+    if (!T.node_aabb.alloc((size_t)nn * 6)) { err = "out of device memory"; return false; }
+    CK(hipMemsetAsync(T.node_aabb.p, 0, sizeof(float) * 6 * nn, st));
+    {
+        std::vector<int> ln, ob, oc;
+        for (int i = 0; i < nn; i++) if (T.nodes[i].kind == N_LEAF) { ln.push_back(i); ob.push_back(T.nodes[i].obj_begin); oc.push_back(T.nodes[i].obj_count); }
+        int nl = (int)ln.size();
+        if (nl) {
+            DevBuf<int> dln, dob, doc;
+            if (!dln.alloc(nl) || !dob.alloc(nl) || !doc.alloc(nl)) { err = "out of device memory"; return false; }
+            CK(hipMemcpyAsync(dln.p, ln.data(), sizeof(int) * nl, hipMemcpyHostToDevice, st));
+            CK(hipMemcpyAsync(dob.p, ob.data(), sizeof(int) * nl, hipMemcpyHostToDevice, st));
+            CK(hipMemcpyAsync(doc.p, oc.data(), sizeof(int) * nl, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_leaf_boxes, dim3((nl + 127) / 128), dim3(128), 0, st, nl, dln.p, dob.p, doc.p, T.perm.p, T.in_aabb.p, T.node_aabb.p);
+            CK(hipGetLastError());
+            CK(hipStreamSynchronize(st));
+        }
+        for (int i = 0; i < nn; i++) if (T.nodes[i].kind == N_SOCKET) {
+            hipLaunchKernelGGL(k_copy_box, dim3(1), dim3(1), 0, st, T.in_aabb.p, N + T.nodes[i].mesh_slot, T.node_aabb.p, i);
+            CK(hipGetLastError());
+        }
+        // depth of every node, then inner nodes deepest first
+        std::vector<int> depth(nn, 0), order_bfs = {0};
+        int maxd = 0;
+        for (size_t q = 0; q < order_bfs.size(); q++) {
+            int x = order_bfs[q];
+            for (int c : T.nodes[x].children) { depth[c] = depth[x] + 1; maxd = std::max(maxd, depth[c]); order_bfs.push_back(c); }
+        }
+        for (int d = maxd; d >= 0; d--) {
+            std::vector<int> nd, cb, cc, ch;
+            for (int i = 0; i < nn; i++) if (depth[i] == d && T.nodes[i].kind == N_INNER && (i == 0 || order_bfs.size() > 0)) {
+                if (i != 0 && depth[i] == 0) continue;
+                nd.push_back(i); cb.push_back((int)ch.size()); cc.push_back((int)T.nodes[i].children.size());
+                for (int c : T.nodes[i].children) ch.push_back(c);
+            }
+            int k = (int)nd.size();
+            if (!k) continue;
+            DevBuf<int> dnd, dcb, dcc, dch;
+            if (!dnd.alloc(k) || !dcb.alloc(k) || !dcc.alloc(k) || !dch.alloc(ch.size())) { err = "out of device memory"; return false; }
+            CK(hipMemcpyAsync(dnd.p, nd.data(), sizeof(int) * k, hipMemcpyHostToDevice, st));
+            CK(hipMemcpyAsync(dcb.p, cb.data(), sizeof(int) * k, hipMemcpyHostToDevice, st));
+            CK(hipMemcpyAsync(dcc.p, cc.data(), sizeof(int) * k, hipMemcpyHostToDevice, st));
+            if (!ch.empty()) CK(hipMemcpyAsync(dch.p, ch.data(), sizeof(int) * ch.size(), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_inner_boxes, dim3((k + 127) / 128), dim3(128), 0, st, k, dnd.p, dcb.p, dcc.p, dch.p, T.node_aabb.p);
+            CK(hipGetLastError());
+            CK(hipStreamSynchronize(st));
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+// index_tree order + node bytes + object id table (pt_bvh_tree.gd:488-524,780-791,910-959)
+bool BvhImpl::flatten(hipStream_t st, uint8_t* node_bytes, int32_t* object_ids, std::string& err) {
+    struct Ref { BvhImpl* tree; int node; };
+    const int total = flat_node_count();
+    std::vector<Ref> flat;
+    flat.reserve(total);
+    // per tree: offset of its boxes in the concatenated box buffer, offset of its ids in the id table
+    std::vector<BvhImpl*> trees = {this};
+    for (auto* m : meshes) trees.push_back(m);
+    std::vector<int> box_off(trees.size()), id_off(trees.size());
+    int bo = 0, io = 0;
+    for (size_t t = 0; t < trees.size(); t++) { box_off[t] = bo; bo += trees[t]->own_nodes(); id_off[t] = io; io += trees[t]->own_object_count; }
+    auto tree_slot = [&](BvhImpl* t) { for (size_t i = 0; i < trees.size(); i++) if (trees[i] == t) return (int)i; return 0; };
+    // leaf -> first object id slot: own leaves in leaf_order, then each mesh's (create_object_ids)
+    std::vector<std::vector<int>> oid(trees.size());
+    for (size_t t = 0; t < trees.size(); t++) {
+        oid[t].assign(trees[t]->own_nodes(), -1);
+        int run = id_off[t];
+        for (int l : trees[t]->leaf_order) { oid[t][l] = run; run += trees[t]->nodes[l].obj_count; }
+    }
+    // flatten: children of a node are consecutive; then each inner child's block, in order (index_subnodes)
+    std::vector<std::vector<int>> pos(trees.size());
+    for (size_t t = 0; t < trees.size(); t++) pos[t].assign(trees[t]->own_nodes(), -1);
+    auto children_of = [&](Ref r, std::vector<Ref>& out) {
+        out.clear();
+        const HNode& nd = r.tree->nodes[r.node];
+        if (nd.kind == N_SOCKET) out.push_back({meshes[nd.mesh_slot], 0});
+        else for (int c : nd.children) out.push_back({r.tree, c});
+    };
+    {
+        flat.push_back({this, 0});
+        pos[0][0] = 0;
+        struct Frame { Ref r; std::vector<Ref> kids; size_t next; };
+        std::vector<Frame> stack;
+        auto open = [&](Ref r) {
+            Frame f; f.r = r; f.next = 0;
+            children_of(r, f.kids);
+            for (Ref k : f.kids) { pos[tree_slot(k.tree)][k.node] = (int)flat.size(); flat.push_back(k); }
+            stack.push_back(std::move(f));
+        };
+        open({this, 0});
+        while (!stack.empty()) {
+            Frame& f = stack.back();
+            if (f.next < f.kids.size()) {
+                Ref k = f.kids[f.next++];
+                if (k.tree->nodes[k.node].kind != N_LEAF) open(k);
+                continue;
+            }
+            stack.pop_back();
+        }
+    }
+    if ((int)flat.size() != total) { err = "flatten: node count mismatch"; return false; }
+    std::vector<int> box_index(total), node_id(total), xform(total);
+    std::vector<unsigned char> empty_root(total, 0);
+    std::vector<Ref> kids;
+    for (int i = 0; i < total; i++) {
+        Ref r = flat[i];
+        const HNode& nd = r.tree->nodes[r.node];
+        int ts = tree_slot(r.tree);
+        box_index[i] = box_off[ts] + r.node;
+        long long idx = 0, size = 0;
+        if (nd.kind == N_LEAF) { idx = -(long long)oid[ts][r.node] - 1; size = nd.obj_count - 1; }
+        else {
+            children_of(r, kids);
+            if (kids.empty()) { empty_root[i] = 1; }
+            else { idx = pos[tree_slot(kids[0].tree)][kids[0].node]; size = (long long)kids.size(); }
+        }
+        idx ^= size << 24;
+        node_id[i] = (int32_t)(uint32_t)(unsigned long long)idx;
+        xform[i] = nd.kind == N_SOCKET ? mesh_index[nd.mesh_slot] : -1;
+    }
+    DevBuf<float> boxes, out;
+    DevBuf<int> d_box, d_id, d_xf, d_ids;
+    DevBuf<unsigned char> d_empty;
+    if (!boxes.alloc((size_t)bo * 6) || !out.alloc((size_t)total * 8) || !d_box.alloc(total) || !d_id.alloc(total) || !d_xf.alloc(total) ||
+        !d_empty.alloc(total) || !d_ids.alloc(std::max(io, 1))) { err = "out of device memory"; return false; }
+    for (size_t t = 0; t < trees.size(); t++)
+        CK(hipMemcpyAsync(boxes.p + (size_t)box_off[t] * 6, trees[t]->node_aabb.p, sizeof(float) * 6 * trees[t]->own_nodes(), hipMemcpyDeviceToDevice, st));
+    CK(hipMemcpyAsync(d_box.p, box_index.data(), sizeof(int) * total, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(d_id.p, node_id.data(), sizeof(int) * total, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(d_xf.p, xform.data(), sizeof(int) * total, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(d_empty.p, empty_root.data(), total, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_encode, dim3((total + 127) / 128), dim3(128), 0, st, total, d_box.p, d_id.p, d_xf.p, d_empty.p, boxes.p, out.p);
+    CK(hipGetLastError());
+    if (node_bytes) CK(hipMemcpyAsync(node_bytes, out.p, (size_t)total * 32, hipMemcpyDeviceToHost, st));
+    // object ids: every leaf's objects at its slot, in leaf order; a leaf's range in perm is contiguous
+    if (object_ids && io > 0) {
+        for (size_t t = 0; t < trees.size(); t++) {
+            BvhImpl* T = trees[t];
+            if (T->n_in == 0) continue;
+            DevBuf<int> gathered;
+            if (!gathered.alloc(T->n_in)) { err = "out of device memory"; return false; }
+            hipLaunchKernelGGL(k_gather_ids, dim3((T->n_in + 255) / 256), dim3(256), 0, st, T->n_in, T->perm.p, T->in_ref.p, gathered.p);
+            CK(hipGetLastError());
+            std::vector<int> h(T->n_in);
+            CK(hipMemcpyAsync(h.data(), gathered.p, sizeof(int) * T->n_in, hipMemcpyDeviceToHost, st));
+            CK(hipStreamSynchronize(st));
+            for (int l : T->leaf_order) {
+                const HNode& nd = T->nodes[l];
+                memcpy(object_ids + oid[t][l], h.data() + nd.obj_begin, sizeof(int) * nd.obj_count);
+            }
+        }
+    }
+    CK(hipStreamSynchronize(st));
+    return true;
+}
+
+std::unique_ptr<PtkBvh> ptk_bvh_build_device(hipStream_t stream, int order, int type, int n_objects,
+                                             const float* aabbs6, const int32_t* object_ids,
+                                             const std::vector<PtkBvh*>& mesh_trees,
+                                             const float* mesh_transforms12, const int32_t* mesh_indices,
                                              std::string& err) {
-    err = "the device BVH builder is not part of this build";
-    return nullptr;
+    if (order > MAXB) { err = "the device builder bins for order <= 8"; return nullptr; }
+    auto T = std::make_unique<BvhImpl>();
+    T->order = order;
+    T->type = type;
+    T->n_objects = n_objects;
+    for (size_t m = 0; m < mesh_trees.size(); m++) {
+        T->meshes.push_back(static_cast<BvhImpl*>(mesh_trees[m]));
+        T->mesh_index.push_back(mesh_indices[m]);
+    }
+    if (!build_tree(stream, *T, aabbs6, object_ids, mesh_transforms12, err)) return nullptr;
+    return T;
 }

@@ -31,7 +31,10 @@ PTK_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 PTK_DEV f3 cross3(f3 a, f3 b) {
     return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
 }
-PTK_DEV float psqrt(float x) { return __fsqrt_rn(x); }
+// Correctly rounded: __builtin_sqrtf lowers to the IEEE sequence under hipcc's
+// default -fhip-fp32-correctly-rounded-divide-sqrt (the Makefile also passes it);
+// __fsqrt_rn would be the 1-ulp native v_sqrt_f32 in this toolchain.
+PTK_DEV float psqrt(float x) { return __builtin_sqrtf(x); }
 PTK_DEV float length3(f3 a) { return psqrt(dot3(a, a)); }
 // normalize(v) = v * (1 / sqrt(dot(v,v)))
 PTK_DEV f3 normalize3(f3 a) {

@@ -160,7 +160,6 @@ def atrium_triangles(n_triangles: int = 262144, seed: int = 7) -> np.ndarray:
     rng = np.random.default_rng(seed)
     L, W, H = 36.0, 16.0, 14.0  # hall extent: x in [-L/2, L/2], z in [-W/2, W/2], y in [0, H]
     parts = []
-    budget = n_triangles
     shell = int(n_triangles * 0.30)
     # shell: 6 faces with cell counts proportional to area
     faces = [
@@ -177,26 +176,37 @@ def atrium_triangles(n_triangles: int = 262144, seed: int = 7) -> np.ndarray:
         lu, lv = np.linalg.norm(f[1]), np.linalg.norm(f[2])
         nu = max(1, int(round(np.sqrt(cells * lu / lv))))
         nv = max(1, cells // nu)
-        parts.append(_quad_grid(f[0], np.array(f[1]) / nu, np.array(f[2]) / nv, nu, nv))
-    # columns: two rows per storey, octagonal prisms subdivided vertically
-    col = []
+        g = _quad_grid(f[0], np.array(f[1]) / nu, np.array(f[2]) / nv, nu, nv)
+        if f[0][1] == H:  # open roof over the courtyard, like the real atrium: the sky lights the hall
+            c = g.mean(axis=1)
+            g = g[~((np.abs(c[:, 0]) < L / 2 - 6.0) & (np.abs(c[:, 2]) < W / 2 - 4.0))]
+        parts.append(g)
+    # columns: two rows per storey, prisms subdivided vertically; detail scales with the budget
     n_cols = 14
+    col_budget = int(n_triangles * 0.22)
+    segs = 12 if n_triangles >= 65536 else 6
+    rings = max(1, col_budget // (4 * n_cols * segs * 2))
+    col = []
     for storey, (y0, y1) in enumerate([(0.0, 6.0), (6.5, 12.0)]):
         for side in (-1, 1):
             for c in range(n_cols):
                 cx = -L / 2 + 2.0 + c * (L - 4.0) / (n_cols - 1)
                 cz = side * (W / 2 - 3.0)
                 r = 0.45 - 0.1 * storey
-                segs, rings = 12, 24
                 ang = np.linspace(0, 2 * np.pi, segs + 1)
                 ys = np.linspace(y0, y1, rings + 1)
-                for a0, a1 in zip(ang[:-1], ang[1:]):
-                    for ya, yb in zip(ys[:-1], ys[1:]):
-                        p = lambda a, y: (cx + r * np.cos(a), y, cz + r * np.sin(a))
-                        col.append([p(a0, ya), p(a1, ya), p(a1, yb)])
-                        col.append([p(a0, ya), p(a1, yb), p(a0, yb)])
-    parts.append(np.array(col))
-    # arches between neighbouring columns (half tori approximated by strips)
+                a0, ya = np.meshgrid(ang[:-1], ys[:-1], indexing="ij")
+                a1, yb = np.meshgrid(ang[1:], ys[1:], indexing="ij")
+
+                def p(a, y):
+                    return np.stack([cx + r * np.cos(a), y, cz + r * np.sin(a)], axis=-1)
+
+                col.append(np.stack([p(a0, ya), p(a1, ya), p(a1, yb)], axis=-2).reshape(-1, 3, 3))
+                col.append(np.stack([p(a0, ya), p(a1, yb), p(a0, yb)], axis=-2).reshape(-1, 3, 3))
+    parts.append(np.concatenate(col))
+    # arches between neighbouring columns (half rings, two strips deep)
+    arch_budget = int(n_triangles * 0.04)
+    steps = max(2, arch_budget // (4 * (n_cols - 1) * 4))
     arch = []
     for y0 in (5.0, 11.0):
         for side in (-1, 1):
@@ -205,16 +215,16 @@ def atrium_triangles(n_triangles: int = 262144, seed: int = 7) -> np.ndarray:
                 x0 = -L / 2 + 2.0 + c * (L - 4.0) / (n_cols - 1)
                 x1 = -L / 2 + 2.0 + (c + 1) * (L - 4.0) / (n_cols - 1)
                 xm, rad = 0.5 * (x0 + x1), 0.5 * (x1 - x0) - 0.3
-                th = np.linspace(0, np.pi, 25)
-                for t0, t1 in zip(th[:-1], th[1:]):
-                    for zo in (-0.35, 0.0):
-                        a = (xm + rad * np.cos(t0), y0 + rad * np.sin(t0), cz + zo)
-                        b = (xm + rad * np.cos(t1), y0 + rad * np.sin(t1), cz + zo)
-                        c2 = (xm + rad * np.cos(t1), y0 + rad * np.sin(t1), cz + zo + 0.35)
-                        d = (xm + rad * np.cos(t0), y0 + rad * np.sin(t0), cz + zo + 0.35)
-                        arch.append([a, b, c2])
-                        arch.append([a, c2, d])
-    parts.append(np.array(arch))
+                th = np.linspace(0, np.pi, steps + 1)
+                t0, t1 = th[:-1], th[1:]
+                for zo in (-0.35, 0.0):
+                    def q(t, z):
+                        return np.stack([xm + rad * np.cos(t), y0 + rad * np.sin(t), np.full_like(t, cz + z)], axis=-1)
+
+                    pa, pb, pc, pd = q(t0, zo), q(t1, zo), q(t1, zo + 0.35), q(t0, zo + 0.35)
+                    arch.append(np.stack([pa, pb, pc], axis=-2))
+                    arch.append(np.stack([pa, pc, pd], axis=-2))
+    parts.append(np.concatenate(arch))
     used = sum(p.shape[0] for p in parts)
     # drapes: wavy vertical sheets across the hall, fine grids
     n_drapes = 6
@@ -222,7 +232,7 @@ def atrium_triangles(n_triangles: int = 262144, seed: int = 7) -> np.ndarray:
     per = drape_budget // n_drapes
     for dgi in range(n_drapes):
         x = -L / 2 + 4.0 + dgi * (L - 8.0) / (n_drapes - 1)
-        nu = max(2, int(np.sqrt(per / 2 * 2.0)))
+        nu = max(2, int(np.sqrt(max(per, 8) / 2 * 2.0)))
         nv = max(2, (per // 2) // nu)
         u = np.linspace(-2.5, 2.5, nu + 1)
         v = np.linspace(7.0, 12.5, nv + 1)
@@ -247,6 +257,15 @@ def atrium_triangles(n_triangles: int = 262144, seed: int = 7) -> np.ndarray:
         parts.append(np.stack([base, base + e1, base + e2], axis=1))
     tris = np.concatenate(parts)[:n_triangles]
     assert tris.shape[0] == n_triangles, tris.shape
+    # No surface is exactly planar: every vertex moves by a few millimetres, by an amount that depends
+    # only on its position (shared vertices stay shared, the hall stays closed).  The reference's
+    # builder bins a node by its box centre inside the list's box grown by 1e-6; a triangle that is
+    # exactly flat on the outermost face of the hall sits on the upper edge of the last bin and trips
+    # the builder's `index < segment_count` assert (pt_bvh_axis_sort.gd:307-308).
+    q = np.round(tris * 1024.0).astype(np.int64)
+    hsh = (q[..., 0] * 73856093) ^ (q[..., 1] * 19349663) ^ (q[..., 2] * 83492791) ^ (seed * 2654435761)
+    jit = np.stack([((hsh >> s) & 1023) for s in (3, 17, 31)], axis=-1).astype(np.float64)
+    tris = tris + (jit / 1023.0 - 0.5) * 0.012
     return tris.astype(np.float32)
 
 

@@ -1,0 +1,125 @@
+"""GPU parity of the BVH builder: node bytes and object id table bit-exact against the CPU
+restatement, through the C ABI (ptk_bvh_build / ptk_bvh_read)."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rd(pta):
+    dev = pta.PtkRenderingDevice(0)
+    yield dev
+    dev.close()
+
+
+def _both(pta, rd, scene, order=8, bvh_type=None):
+    wd = pta.work_dispatcher
+    cpu_nodes, cpu_ids = wd.create_scene_bvh(scene, ob.OracleBvhBuilder(), order, bvh_type)
+    gpu_nodes, gpu_ids = wd.create_scene_bvh(scene, wd.DeviceBvhBuilder(rd), order, bvh_type)
+    return cpu_nodes, cpu_ids, gpu_nodes, gpu_ids
+
+
+def _check(name, cpu_nodes, cpu_ids, gpu_nodes, gpu_ids):
+    assert len(gpu_nodes) == len(cpu_nodes), f"{name}: node count {len(gpu_nodes) // 32} vs {len(cpu_nodes) // 32}"
+    assert np.array_equal(np.asarray(gpu_ids), np.asarray(cpu_ids)), f"{name}: object id order differs"
+    if gpu_nodes != cpu_nodes:
+        a = np.frombuffer(gpu_nodes, dtype=np.uint32).reshape(-1, 8)
+        b = np.frombuffer(cpu_nodes, dtype=np.uint32).reshape(-1, 8)
+        bad = np.argwhere((a != b).any(1))[:5].ravel().tolist()
+        raise AssertionError(f"{name}: node bytes differ, first nodes {bad}")
+    print(f"{name}: {len(cpu_nodes) // 32} nodes, {len(cpu_ids)} ids bit-exact")
+
+
+@pytest.mark.parametrize("name", ["sphere_scene1", "benchmark_random_scene", "fake_cornell_box", "sphere_scene3",
+                                  "dragon_test", "test_scene_bvh_a", "test_scene_bvh_b"])
+@pytest.mark.parametrize("bvh_type", [1, 2, 3, 4])
+def test_fixture_scenes_all_types(pta, rd, golden_dir, name, bvh_type):
+    """Every fixture scene with X / Y / Z / longest-axis trees.  The random scene's Y tree sorts 484
+    equal keys (every small sphere sits at y = 0.2): the order then comes from the sort's tie handling."""
+    scene = pta.scenes.load_fixture_scene(name, golden_dir)
+    if bvh_type != 1:
+        for m in scene.meshes:
+            m.bvh_type = bvh_type
+    _check(f"{name}/type{bvh_type}", *_both(pta, rd, scene, 8, bvh_type))
+
+
+@pytest.mark.parametrize("order", [2, 3, 4, 8])
+def test_orders(pta, rd, golden_dir, order):
+    scene = pta.scenes.load_fixture_scene("benchmark_random_scene", golden_dir)
+    _check(f"random/order{order}", *_both(pta, rd, scene, order, 4))
+
+
+def _grid_triangles(n_side, seed):
+    """Axis-aligned grid of triangles with heavy exact ties in every centre coordinate."""
+    rng = np.random.default_rng(seed)
+    i, j, k = np.meshgrid(np.arange(n_side), np.arange(n_side), np.arange(3), indexing="ij")
+    base = np.stack([i, k * 0.5, j], axis=-1).reshape(-1, 3).astype(np.float32)
+    e1 = np.array([0.75, 0.0, 0.0], np.float32)
+    e2 = np.array([0.0, 0.25, 0.75], np.float32)
+    tris = np.stack([base, base + e1, base + e2], axis=1)
+    return tris[rng.permutation(tris.shape[0])]
+
+
+@pytest.mark.parametrize("bvh_type", [1, 4])
+def test_tie_heavy_grid(pta, rd, bvh_type):
+    """3 x 40 x 40 grid: thousands of equal sort keys; exercises the emulated unstable sort on long
+    runs of ties, and the single-occupied-bin halving."""
+    sc = pta.scene
+    scene = sc.PTScene(default_bvh=bvh_type)
+    mesh = sc.PTMesh(bvh_type=bvh_type)
+    mesh.scene = scene
+    mesh.triangle_set = sc.PTTriangleSet(vertices=_grid_triangles(40, 5))
+    scene.add_mesh(mesh)
+    scene.add_object(sc.PTSphere(radius=0.5))
+    _check(f"grid/type{bvh_type}", *_both(pta, rd, scene, 8, bvh_type))
+
+
+def test_identical_objects_depth_limit(pta, rd):
+    """200 identical spheres: every split lands in one bin, lists are halved until they fit."""
+    sc, gm = pta.scene, pta.godot_math
+    scene = sc.PTScene()
+    for _ in range(200):
+        scene.add_object(sc.PTSphere(transform=gm.Transform3D(origin=(1.0, 2.0, 3.0)), radius=0.25))
+    _check("identical", *_both(pta, rd, scene, 8, 4))
+
+
+def test_atrium_64k(pta, rd):
+    """65 536-triangle stand-in: deep recursion, large sorts, one mesh socket."""
+    scene = pta.scenes.atrium_scene(65536, seed=7)
+    _check("atrium64k", *_both(pta, rd, scene, 8, 4))
+
+
+def test_atrium_full_size(pta, rd):
+    """The full 262 144-triangle benchmark scene."""
+    scene = pta.scenes.atrium_scene(262144, seed=7)
+    _check("atrium262k", *_both(pta, rd, scene, 8, 4))
+
+
+def test_many_meshes(pta, rd):
+    """Several instanced meshes next to scene-level objects: sockets inside terminal lists."""
+    sc, gm = pta.scene, pta.godot_math
+    rng = np.random.default_rng(11)
+    scene = sc.PTScene(default_bvh=4)
+    for i in range(5):
+        scene.add_object(sc.PTSphere(transform=gm.Transform3D(origin=tuple(rng.uniform(-6, 6, 3))), radius=float(rng.uniform(0.2, 1.0))))
+    for m in range(11):
+        rot = gm.Transform3D.looking_at(tuple(rng.uniform(-8, 8, 3)), tuple(rng.uniform(-1, 1, 3)))
+        mesh = sc.PTMesh(transform=rot, bvh_type=4)
+        mesh.scene = scene
+        base = rng.uniform(-1, 1, (300, 1, 3)).astype(np.float32)
+        mesh.triangle_set = sc.PTTriangleSet(vertices=(base + rng.normal(0, 0.1, (300, 3, 3))).astype(np.float32))
+        scene.add_mesh(mesh)
+    _check("meshes", *_both(pta, rd, scene, 8, 4))
+    _check("meshes/x", *_both(pta, rd, scene, 8, 1))
+
+
+def test_builder_errors(pta, rd):
+    with pytest.raises(pta.PtkError):
+        rd.bvh_build(8, 1, np.zeros((0, 6), np.float32), np.zeros(0, np.int32))
+    with pytest.raises(pta.PtkError):
+        rd.bvh_build(1, 1, np.ones((2, 6), np.float32), np.zeros(2, np.int32))
+    with pytest.raises(pta.PtkError):
+        rd.bvh_build(8, 9, np.ones((2, 6), np.float32), np.zeros(2, np.int32))
