@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Benchmark of the render hot path: Mrays/s and ms/frame at 1920x1080 on the Sponza stand-in.
+
+A step is one dispatch of the render kernel = 1 sample per pixel over the full frame (depth 8,
+refraction bounces 4) of the seeded 262 144-triangle atrium (the reference's sponza-crytek.blend is
+not in its checkout), one PTMesh with a longest-axis order-8 BVH built by the HIP builder.  A ray is
+one path segment = one closest-hit search (check_ray_hit_BVH, shaders/ray_tracer.comp:1200).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 runs under torch.distributed.run, one process per GPU: the scene is replicated, every rank
+renders its own batch of K samples of the full frame (weak scaling) and the per-GPU accumulation
+images are combined once per batch with an RCCL reduce inside the timed region.
+
+Rank 0 prints one JSON line; see the keys "roofline" (dominant kernel: algorithmic bytes / measured
+kernel time against the 8 TB/s HBM peak) and "cpu_baseline" (the CPU restatement of the shader on
+the host cores, one full-frame dispatch).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT = 1920, 1080
+N_TRIANGLES = 262144
+DEPTH, REFRACTION_BOUNCES = 8, 4
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def algorithmic_bytes(cnt, n_planes_padded, pixels):
+    """Bytes the reference's layout makes one dispatch touch, no cache credit:
+    32 B per box test, 4 B per object id, 32 B per sphere test, 48 B per triangle test (three points),
+    32 B per plane record scanned per ray, the hit record (32 / 32 / 80 B) and 64 B material per
+    resolved hit, 64 B per mesh-socket matrix, 32 B image read+write and 128 B push constants per pixel."""
+    c = {k: int(v) for k, v in cnt.items()}
+    return (32 * c["box_tests"] + 4 * c["obj_tests"] + 32 * c["sphere_tests"] + 48 * c["tri_tests"]
+            + 32 * n_planes_padded * c["rays"] + 32 * c["hit_sphere"] + 32 * c["hit_plane"] + 80 * c["hit_triangle"]
+            + 64 * c["material_fetch"] + 64 * c["sockets"] + pixels * (32 + 128))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pta = importlib.import_module("path-tracer_amd")
+    wd = pta.work_dispatcher
+    scene = pta.scenes.atrium_scene(N_TRIANGLES, seed=7)
+    rd = pta.PtkRenderingDevice(local_rank if world > 1 else 0)
+    disp = wd.PTWorkDispatcher(rd)
+    disp.set_scene(scene)
+    t0 = time.time()
+    disp.create_buffers(WIDTH, HEIGHT, order=8)  # BVH built on the GPU
+    build_s = time.time() - t0
+    disp.load_shader(refraction_mode=2, use_emission=False, early_t_break=False)
+    win = wd.PTRenderWindow(render_width=WIDTH, render_height=HEIGHT, max_ray_depth=DEPTH,
+                            max_refraction_bounces=REFRACTION_BOUNCES, max_samples=args.steps)
+    pixels = WIDTH * HEIGHT
+    n_planes_padded = len(disp.packed.planes) // 32
+
+    def sample_index(k):
+        # every rank renders its own disjoint set of samples
+        return rank * args.steps + k
+
+    # --- untimed: count the rays and traversal work of exactly the K timed steps (traced kernel variant)
+    rd.trace_enable(pta.rendering_device.PTK_TRACE_COUNTERS)
+    counters = np.zeros(pta.rendering_device.PTK_NCOUNTERS, dtype=np.int64)
+    for k in range(args.steps):
+        win.frame = k
+        disp.create_compute_list(win, scene.camera, wd.sample_time(sample_index(k)), sync=True)
+        counters += rd.trace_read_counters(disp.image_buffer).reshape(-1, pta.rendering_device.PTK_NCOUNTERS).sum(0)
+    rd.trace_enable(0)
+    cnt = dict(zip(pta.rendering_device.COUNTER_NAMES, counters.tolist()))
+    rays_local = cnt["rays"]
+
+    reduce_buf = None
+    if world > 1:
+        reduce_buf = torch.empty((HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+
+    def run_steps(n, first_frame=0):
+        for k in range(n):
+            win.frame = first_frame + k
+            disp.create_compute_list(win, scene.camera, wd.sample_time(sample_index(k)))
+        if world > 1:
+            # combine the per-GPU accumulators: mean over ranks of each rank's running mean
+            rd.image_copy_device(disp.image_buffer, reduce_buf.data_ptr(), reduce_buf.numel() * 4, to_image=False)
+            dist.reduce(reduce_buf, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                reduce_buf.mul_(1.0 / world)
+                torch.cuda.synchronize()
+                rd.image_copy_device(disp.image_buffer, reduce_buf.data_ptr(), reduce_buf.numel() * 4, to_image=True)
+        rd.sync()
+
+    run_steps(args.warmup)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t_start = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    kernel_ms = rd.dispatch_history_ms(min(args.steps, 64))
+
+    rays_total = rays_local
+    if world > 1:
+        t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0].item())
+        rays_total = int(t[1].item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    avg_kernel_ms = float(np.mean(kernel_ms))
+    bytes_per_launch = algorithmic_bytes(cnt, n_planes_padded, pixels * args.steps) / args.steps
+    achieved_gbs = bytes_per_launch / (avg_kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "Mrays/s (path segments/s) at 1920x1080 Sponza",
+        "value": rays_total / elapsed / 1e6,
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "sponza_standin_atrium_262144tri_1920x1080_1spp_per_step_depth8_refr4_bvh_xyz_order8",
+            "width": WIDTH, "height": HEIGHT, "triangles": N_TRIANGLES, "max_ray_depth": DEPTH,
+            "max_refraction_bounces": REFRACTION_BOUNCES, "rays_per_step": rays_local / args.steps,
+            "bvh_nodes": len(disp.packed.bvh) // 32, "bvh_build_s": build_s,
+            "parallelism": "sample batches per GPU, scene replicated, RCCL reduce of accumulators" if world > 1 else "single GPU",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "ptk_render_kernel",
+            "achieved": achieved_gbs,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved_gbs / HBM_PEAK_GBS,
+            "traffic": None,
+            "bytes_per_launch": bytes_per_launch,
+            "bytes_per_ray": bytes_per_launch * args.steps / max(rays_local, 1),
+            "kernel_ms_avg": avg_kernel_ms,
+        },
+    }
+
+    if not args.no_cpu_baseline:
+        # CPU baseline: the oracle (a restatement of ray_tracer.comp, not Godot/lavapipe, which do not
+        # exist on this box) renders ONE full-frame dispatch of the same workload on the host cores.
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_binding as ob
+
+        cores = min(os.cpu_count() or 1, 16)
+        img = np.zeros((HEIGHT, WIDTH, 4), np.float32)
+        win.frame = 0
+        push = wd.push_constant_bytes(scene.camera, win, wd.sample_time(0))
+        c0 = time.perf_counter()
+        res = ob.render(disp.packed, push, img, WIDTH // 8, HEIGHT // 8, nthreads=cores)
+        cpu_s = time.perf_counter() - c0
+        out["cpu_baseline"] = {
+            "value": float(res["totals"][0]) / cpu_s / 1e6,
+            "unit": "Mrays/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": "one full 1920x1080 dispatch (1 spp, depth 8) of the same scene and BVH; %.1f s of CPU work" % cpu_s,
+            "ms_per_step": cpu_s * 1e3,
+        }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

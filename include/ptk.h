@@ -137,6 +137,13 @@ int ptk_trace_read(ptk_ctx* ctx, int which, void* dst, size_t nbytes);
 /* Duration in milliseconds of the last ptk_dispatch's kernel, from HIP events
  * recorded on the context's stream around the launch (blocks until it ended). */
 int ptk_last_dispatch_ms(ptk_ctx* ctx, float* ms);
+/* Same for the last n dispatches (n <= 64), ms[0] the oldest. */
+int ptk_dispatch_history_ms(ptk_ctx* ctx, float* ms, int n);
+
+/* Multi-GPU glue; no counterpart in the reference, which renders on one device.  Copies the rgba32f
+ * image to (to_image = 0) or from (to_image = 1) a device pointer owned by the caller on the same GPU
+ * (e.g. the torch tensor handed to an RCCL reduce / gather), without a trip through host memory. */
+int ptk_image_copy_device(ptk_ctx* ctx, uint64_t image, void* device_ptr, size_t nbytes, int to_image);
 
 #ifdef __cplusplus
 }

@@ -40,8 +40,9 @@ struct Slot {
 struct ptk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool have_timing = false;
+    static constexpr int kTimingRing = 64;
+    hipEvent_t ev0[kTimingRing] = {nullptr}, ev1[kTimingRing] = {nullptr};
+    long long dispatch_count = 0;
     std::string error;
     std::map<uint64_t, std::unique_ptr<Object>> objects;
     uint64_t next_handle = 1;
@@ -119,8 +120,10 @@ ptk_ctx* ptk_create(int device_ordinal) {
     }
     auto* ctx = new ptk_ctx();
     ctx->device = device_ordinal;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+    bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < ptk_ctx::kTimingRing; i++)
+        ok = hipEventCreate(&ctx->ev0[i]) == hipSuccess && hipEventCreate(&ctx->ev1[i]) == hipSuccess;
+    if (!ok) {
         fail(nullptr, PTK_E_HIP, "stream/event creation failed");
         delete ctx;
         return nullptr;
@@ -146,8 +149,10 @@ void ptk_destroy(ptk_ctx* ctx) {
     if (ctx->d_spill_t) (void)hipFree(ctx->d_spill_t);
     if (ctx->d_trace_primary) (void)hipFree(ctx->d_trace_primary);
     if (ctx->d_trace_counters) (void)hipFree(ctx->d_trace_counters);
-    (void)hipEventDestroy(ctx->ev0);
-    (void)hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < ptk_ctx::kTimingRing; i++) {
+        if (ctx->ev0[i]) (void)hipEventDestroy(ctx->ev0[i]);
+        if (ctx->ev1[i]) (void)hipEventDestroy(ctx->ev1[i]);
+    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -582,19 +587,38 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         P.trace_counters = (ctx->trace_flags & PTK_TRACE_COUNTERS) ? ctx->d_trace_counters : nullptr;
     }
 
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    const int slot = (int)(ctx->dispatch_count % ptk_ctx::kTimingRing);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
     HIP_TRY(ctx, ptk_launch_render(&P, groups_x, groups_y, trace, ctx->early_t_break, lds_bytes, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->have_timing = true;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
+    ctx->dispatch_count++;
     return PTK_OK;
 }
 
-int ptk_last_dispatch_ms(ptk_ctx* ctx, float* ms) {
-    if (!ctx || !ms) return PTK_E_INVALID;
-    if (!ctx->have_timing) return fail(ctx, PTK_E_STATE, "no dispatch has been timed yet");
+int ptk_dispatch_history_ms(ptk_ctx* ctx, float* ms, int n) {
+    if (!ctx || !ms || n <= 0) return PTK_E_INVALID;
+    if (n > ptk_ctx::kTimingRing) return fail(ctx, PTK_E_INVALID, "at most %d dispatches are remembered", ptk_ctx::kTimingRing);
+    if (ctx->dispatch_count < n) return fail(ctx, PTK_E_STATE, "only %lld dispatches have run", ctx->dispatch_count);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
-    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    for (int k = 0; k < n; k++) {  // ms[0] = oldest of the last n
+        int slot = (int)((ctx->dispatch_count - n + k) % ptk_ctx::kTimingRing);
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev1[slot]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms[k], ctx->ev0[slot], ctx->ev1[slot]));
+    }
+    return PTK_OK;
+}
+
+int ptk_last_dispatch_ms(ptk_ctx* ctx, float* ms) { return ptk_dispatch_history_ms(ctx, ms, 1); }
+
+int ptk_image_copy_device(ptk_ctx* ctx, uint64_t image, void* device_ptr, size_t nbytes, int to_image) {
+    if (!ctx) return PTK_E_INVALID;
+    Object* o = find(ctx, image, Kind::Image);
+    if (!o) return fail(ctx, PTK_E_INVALID, "unknown image handle");
+    if (!device_ptr || nbytes != o->nbytes) return fail(ctx, PTK_E_INVALID, "image copy needs exactly %zu bytes", o->nbytes);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (to_image) HIP_TRY(ctx, hipMemcpyAsync(o->dev, device_ptr, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    else HIP_TRY(ctx, hipMemcpyAsync(device_ptr, o->dev, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PTK_OK;
 }
 

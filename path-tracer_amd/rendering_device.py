@@ -28,7 +28,7 @@ EXPORTS = [
     "ptk_create", "ptk_destroy", "ptk_last_error", "ptk_configure", "ptk_buffer_create", "ptk_buffer_update",
     "ptk_buffer_read", "ptk_image_create", "ptk_image_read", "ptk_image_update", "ptk_texture_create",
     "ptk_dispatch", "ptk_sync", "ptk_free", "ptk_bvh_build", "ptk_bvh_sizes", "ptk_bvh_read",
-    "ptk_trace_enable", "ptk_trace_read", "ptk_last_dispatch_ms",
+    "ptk_trace_enable", "ptk_trace_read", "ptk_last_dispatch_ms", "ptk_dispatch_history_ms", "ptk_image_copy_device",
 ]
 
 _lib = None
@@ -87,6 +87,10 @@ def load_library() -> C.CDLL:
     lib.ptk_trace_read.argtypes = [vp, C.c_int, vp, C.c_size_t]
     lib.ptk_last_dispatch_ms.restype = C.c_int
     lib.ptk_last_dispatch_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.ptk_dispatch_history_ms.restype = C.c_int
+    lib.ptk_dispatch_history_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    lib.ptk_image_copy_device.restype = C.c_int
+    lib.ptk_image_copy_device.argtypes = [vp, u64, vp, C.c_size_t, C.c_int]
     _lib = lib
     return lib
 
@@ -230,6 +234,14 @@ class PtkRenderingDevice:
         out = np.empty((h, w, PTK_NCOUNTERS), dtype=np.int32)
         self._check(self.lib.ptk_trace_read(self.ctx, PTK_TRACE_COUNTERS, out.ctypes.data, out.nbytes), "ptk_trace_read")
         return out
+
+    def dispatch_history_ms(self, n: int):
+        arr = (C.c_float * n)()
+        self._check(self.lib.ptk_dispatch_history_ms(self.ctx, arr, n), "ptk_dispatch_history_ms")
+        return [float(x) for x in arr]
+
+    def image_copy_device(self, image: int, device_ptr: int, nbytes: int, to_image: bool):
+        self._check(self.lib.ptk_image_copy_device(self.ctx, image, device_ptr, nbytes, int(to_image)), "ptk_image_copy_device")
 
     def last_dispatch_ms(self) -> float:
         ms = C.c_float(0)
