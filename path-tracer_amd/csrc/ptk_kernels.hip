@@ -386,6 +386,161 @@ PTK_DEV Hit check_ray_hit_bvh(const PtkParams& P, Lane& L, Ray& ray, const Stack
     return h;
 }
 
+// ---- phase-coherent traversal ------------------------------------------------------------------
+// Same per-lane order of node pops, box tests and object tests as the loop above, but the wave only
+// runs one kind of step at a time: in every round the lanes whose next node is an inner node (or a
+// mesh socket) and the lanes whose next node is a leaf are counted by ballot, and the larger group
+// advances while the other waits.  A lane's own sequence is untouched, so results are identical; the
+// wave no longer pays the inner-node code and the leaf code in every iteration.  The next node to
+// visit stays in a register (`cur`): the nearest accepted child is not pushed and popped again.
+constexpr uint32_t ENTRY_NONE = 0x7E000000u;  // "inner node with 126 children": never a real entry
+
+// slab test without early returns; same value as hit_aabb (a failed axis makes the result -1).
+PTK_DEV float hit_aabb_bl(float4 bmin, float4 bmax, f3 o, f3 inv, int neg_mask, float start, float end) {
+    float t0, t1;
+    bool fail = false;
+#define PTK_SLAB2(MINV, MAXV, O, INV, BIT)                                         \
+    t0 = ((MINV) - (O)) * (INV);                                                   \
+    t1 = ((MAXV) - (O)) * (INV);                                                   \
+    {                                                                              \
+        float a_ = t0 + t1, b_ = a_ - t1, c_ = a_ - b_;                            \
+        bool n_ = (neg_mask & (BIT)) != 0;                                         \
+        t0 = n_ ? c_ : t0;                                                         \
+        t1 = n_ ? b_ : t1;                                                         \
+    }                                                                              \
+    start = (t0 > start) ? t0 : start;                                             \
+    end = (t1 < end) ? t1 : end;                                                   \
+    fail = fail || (end <= start);
+    PTK_SLAB2(bmin.x, bmax.x, o.x, inv.x, 1)
+    PTK_SLAB2(bmin.y, bmax.y, o.y, inv.y, 2)
+    PTK_SLAB2(bmin.z, bmax.z, o.z, inv.z, 4)
+#undef PTK_SLAB2
+    return fail ? -1.0f : start;
+}
+
+template <bool TRACE>
+PTK_DEV Hit check_ray_hit_bvh2(const PtkParams& P, Lane& L, Ray& ray, const Stack& S, int* cnt) {
+    Hit h;
+    h.hit = 0; h.object_id = 0; h.transform_index = -1; h.u = 0.0f; h.v = 0.0f;
+    for (int i = 0; i < P.n_live_planes; ++i) hit_plane(P, ray, h, P.live_planes[i], -1);
+
+    f3 inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    int neg = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
+
+    uint32_t cur = ENTRY_NONE;
+    int sp = 0;
+    {
+        float4 rmin = P.nodes[0], rmax = P.nodes[1];
+        L.node_hit_count++;
+        float root_hit = hit_aabb_bl(rmin, rmax, ray.o, inv, neg, ray.start, ray.end);
+        if (in_range(root_hit, ray.start, ray.end)) cur = ((int)fbits(rmax.w) >= 0) ? SOCKET_MARK : fbits(rmin.w);
+    }
+    bool in_mesh = false;
+    int sub_base = 0;
+    int cur_xf = -1;
+    f3 w_o = ray.o, w_d = ray.d;  // world ray while inside a mesh
+    float w_start = ray.start;
+    float dir_len = 1.0f;
+
+    for (;;) {
+        const bool has = cur != ENTRY_NONE;
+        const bool is_leaf = has && ((int)cur <= 0);
+        const bool is_inner = has && !is_leaf;
+        const unsigned long long mi = __ballot(is_inner), ml = __ballot(is_leaf);
+        if ((mi | ml) == 0ull) break;
+        bool refill = false;
+        if (__popcll(mi) >= __popcll(ml)) {
+            if (is_inner) {
+                if ((cur & 0xFF000000u) == SOCKET_MARK) {
+                    // world level: enter the mesh (:1286-1313); its root is the next node
+                    int self = (int)(cur & 0x00FFFFFFu);
+                    float4 smin = P.nodes[(size_t)self * 2], smax = P.nodes[(size_t)self * 2 + 1];
+                    int node_index = bfe_i((int)fbits(smin.w), 0, 24);
+                    int xf = (int)fbits(smax.w);
+                    m44 M = load_xform(P, xf);
+                    if (TRACE) cnt[PTK_CNT_SOCKETS]++;
+                    w_o = ray.o; w_d = ray.d; w_start = ray.start;
+                    f3 unnorm = mul_mv(M, ray.d, 0.0f);
+                    dir_len = length3(unnorm);
+                    f3 no = mul_mv(M, ray.o, 1.0f);
+                    ray.d = div3(unnorm, dir_len);
+                    ray.o = no;
+                    ray.end = ray.end * dir_len;
+                    ray.start = ray.start * dir_len;
+                    inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+                    neg = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
+                    sub_base = sp;
+                    cur_xf = xf;
+                    in_mesh = true;
+                    cur = fbits(P.nodes[(size_t)node_index * 2].w);
+                } else {
+                    const int node_index = bfe_i((int)cur, 0, 24);
+                    const int node_size = iabs(bfe_i((int)cur, 24, 8));
+                    float ts[PTK_MAX_WIDTH];
+                    uint32_t es[PTK_MAX_WIDTH];
+                    int added = 0;
+#pragma unroll
+                    for (int l = 0; l < PTK_MAX_WIDTH; l++) {
+                        const bool v = l < node_size;
+                        const size_t ci = (size_t)(node_index + (v ? l : 0)) * 2;
+                        const float4 cmin = P.nodes[ci];
+                        const float4 cmax = P.nodes[ci + 1];
+                        const float t = hit_aabb_bl(cmin, cmax, ray.o, inv, neg, ray.start, ray.end);
+                        const bool acc = v && in_range(t, ray.start, ray.end);
+                        ts[l] = acc ? t : PT_INF;
+                        const bool sock = !in_mesh && ((int)fbits(cmax.w) >= 0);
+                        es[l] = sock ? (SOCKET_MARK | (uint32_t)(node_index + l)) : fbits(cmin.w);
+                        added += acc ? 1 : 0;
+                        L.node_hit_count += v ? 1 : 0;
+                    }
+                    // rank r goes to stack slot sp + added - 1 - r; rank 0 (nearest) stays in `cur`
+                    cur = ENTRY_NONE;
+#pragma unroll
+                    for (int l = 0; l < PTK_MAX_WIDTH; l++) {
+                        int rank = 0;
+#pragma unroll
+                        for (int j = 0; j < PTK_MAX_WIDTH; j++) {
+                            if (j < l) rank += (ts[j] <= ts[l]) ? 1 : 0;
+                            else if (j > l) rank += (ts[j] < ts[l]) ? 1 : 0;
+                        }
+                        if (ts[l] < PT_INF) {
+                            if (rank == 0) cur = es[l];
+                            else st_write(S, sp + added - 1 - rank, (int)es[l]);
+                        }
+                    }
+                    sp += (added > 0) ? added - 1 : 0;
+                    refill = added == 0;
+                }
+            }
+        } else {
+            if (is_leaf) {
+                const int node_index = bfe_i((int)cur, 0, 24);
+                const int node_size = iabs(bfe_i((int)cur, 24, 8));
+                const int base = iabs(node_index) - 1;
+                for (int k = 0; k < node_size; k++) {
+                    hit_object<TRACE>(P, L, ray, h, P.object_ids[base + k], cur_xf, cnt);
+                }
+                refill = true;
+            }
+        }
+        if (refill) {
+            // next node of this lane: pop; an empty mesh sub-stack first maps the ray back (:1309-1310)
+            cur = ENTRY_NONE;
+            if (in_mesh && sp <= sub_base) {
+                float local_end = ray.end;
+                ray.o = w_o; ray.d = w_d; ray.start = w_start;
+                ray.end = local_end / dir_len;
+                inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+                neg = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
+                in_mesh = false;
+                cur_xf = -1;
+            }
+            if (sp > 0) cur = (uint32_t)st_read(S, --sp);
+        }
+    }
+    return h;
+}
+
 // Brute-force closest hit when USE_BVH is off, :1093-1101.
 template <bool TRACE>
 PTK_DEV Hit check_ray_hit_all(const PtkParams& P, Ray& ray, int* cnt) {
@@ -701,7 +856,10 @@ __global__ __launch_bounds__(64) void ptk_render_kernel(const PtkParams P) {
     }
     for (; i < push.max_default_depth + L.refraction_bounces; i++) {
         if (TRACE) cnt[PTK_CNT_RAYS]++;
-        Hit h = use_bvh ? check_ray_hit_bvh<TRACE, EARLY_T>(P, L, nr, S, ST, cnt) : check_ray_hit_all<TRACE>(P, nr, cnt);
+        Hit h;
+        if (!use_bvh) h = check_ray_hit_all<TRACE>(P, nr, cnt);
+        else if (EARLY_T) h = check_ray_hit_bvh<TRACE, EARLY_T>(P, L, nr, S, ST, cnt);
+        else h = check_ray_hit_bvh2<TRACE>(P, L, nr, S, cnt);
         if (first) { primary = h.hit ? h.object_id : -1; first = false; }
         if (!h.hit) {
             float4 sky = P.use_emission ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(0.7f, 0.7f, 0.9f, 1.0f);
