@@ -140,6 +140,20 @@ int ptk_last_dispatch_ms(ptk_ctx* ctx, float* ms);
 /* Same for the last n dispatches (n <= 64), ms[0] the oldest. */
 int ptk_dispatch_history_ms(ptk_ctx* ctx, float* ms, int n);
 
+/* Schedule selection; no counterpart in the reference, where the driver's shader compiler owns the
+ * schedule.  The library renders a dispatch either with one kernel that runs a pixel's whole bounce
+ * loop (ray_tracer.comp:1553-1635 as written) or as a wavefront pipeline (one traversal launch and one
+ * shading launch per bounce over ray queues in device memory).  Both produce the same image bit for
+ * bit.  AUTO takes the wavefront pipeline whenever it covers the dispatch: plain render mode, BVH
+ * flag set, no tracing, no early-t variant.  WAVEFRONT makes ptk_dispatch fail with
+ * PTK_E_UNSUPPORTED where AUTO would fall back. */
+enum { PTK_RENDERER_AUTO = 0, PTK_RENDERER_SINGLE_KERNEL = 1, PTK_RENDERER_WAVEFRONT = 2 };
+int ptk_set_renderer(ptk_ctx* ctx, int renderer);
+/* Durations (ms) of the traversal-kernel launches of the dispatch `back` calls ago (0 = the last
+ * one), from HIP events on the context's stream.  *n_launches = number of launches (0 when that
+ * dispatch used the one-kernel renderer); ms needs room for that many. */
+int ptk_dispatch_traverse_ms(ptk_ctx* ctx, int back, float* ms, int capacity, int* n_launches);
+
 /* Multi-GPU glue; no counterpart in the reference, which renders on one device.  Copies the rgba32f
  * image to (to_image = 0) or from (to_image = 1) a device pointer owned by the caller on the same GPU
  * (e.g. the torch tensor handed to an RCCL reduce / gather), without a trip through host memory. */

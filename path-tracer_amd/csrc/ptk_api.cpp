@@ -64,6 +64,17 @@ struct ptk_ctx {
     int* d_spill = nullptr;
     int* d_spill_t = nullptr;
     size_t spill_ints = 0;
+    // wavefront renderer
+    int renderer = PTK_RENDERER_AUTO;
+    bool wf_ok = false;            // scene has no mesh socket below another mesh socket
+    float4* d_rt_nodes = nullptr;  // nodes with traversal entries in the w words
+    void* d_wf = nullptr;          // queues + path state, one allocation
+    size_t wf_slots = 0;
+    int* d_wf_spill = nullptr;
+    size_t wf_spill_ints = 0;
+    int n_cus = 0;
+    hipEvent_t* wf_ev[kTimingRing] = {nullptr};  // per dispatch slot: 2 events per traversal launch
+    int wf_iters[kTimingRing] = {0};            // traversal launches of that dispatch (0: one-kernel renderer)
     // tracing
     int trace_flags = 0;
     int* d_trace_primary = nullptr;
@@ -123,6 +134,9 @@ ptk_ctx* ptk_create(int device_ordinal) {
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < ptk_ctx::kTimingRing; i++)
         ok = hipEventCreate(&ctx->ev0[i]) == hipSuccess && hipEventCreate(&ctx->ev1[i]) == hipSuccess;
+    hipDeviceProp_t prop;
+    ok = ok && hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess;
+    if (ok) ctx->n_cus = prop.multiProcessorCount;
     if (!ok) {
         fail(nullptr, PTK_E_HIP, "stream/event creation failed");
         delete ctx;
@@ -149,7 +163,14 @@ void ptk_destroy(ptk_ctx* ctx) {
     if (ctx->d_spill_t) (void)hipFree(ctx->d_spill_t);
     if (ctx->d_trace_primary) (void)hipFree(ctx->d_trace_primary);
     if (ctx->d_trace_counters) (void)hipFree(ctx->d_trace_counters);
+    if (ctx->d_rt_nodes) (void)hipFree(ctx->d_rt_nodes);
+    if (ctx->d_wf) (void)hipFree(ctx->d_wf);
+    if (ctx->d_wf_spill) (void)hipFree(ctx->d_wf_spill);
     for (int i = 0; i < ptk_ctx::kTimingRing; i++) {
+        if (ctx->wf_ev[i]) {
+            for (int k = 0; k < 2 * PTK_WF_MAX_ITER; k++) (void)hipEventDestroy(ctx->wf_ev[i][k]);
+            delete[] ctx->wf_ev[i];
+        }
         if (ctx->ev0[i]) (void)hipEventDestroy(ctx->ev0[i]);
         if (ctx->ev1[i]) (void)hipEventDestroy(ctx->ev1[i]);
     }
@@ -388,6 +409,8 @@ static int validate_scene(ptk_ctx* ctx) {
     // while the subtree of a popped node is processed: all k children are pushed
     // at once, then each is popped with up to k-1 siblings still below it.
     std::vector<uint8_t> visited((size_t)n_nodes, 0);
+    std::vector<uint8_t> rt_nodes(nodes->shadow.begin(), nodes->shadow.begin() + (size_t)n_nodes * 32);
+    bool wf_ok = true;
     std::string walk_error;
     int walk_code = PTK_OK;
     struct Walker {
@@ -397,7 +420,8 @@ static int validate_scene(ptk_ctx* ctx) {
         bool bad(int c, const char* fmt, int a = 0, int b = 0, int d = 0) {
             char buf[256]; snprintf(buf, sizeof buf, fmt, a, b, d); err = buf; code = c; return false;
         }
-        bool need(int i, int depth, int& out) {
+        std::vector<uint8_t>& rt; bool& wf_ok;
+        bool need(int i, int depth, bool in_mesh, int& out) {
             if (i < 0 || i >= n_nodes) return bad(PTK_E_INVALID, "BVH references node %d outside the buffer (%d nodes)", i, n_nodes);
             if (visited[i]) return bad(PTK_E_INVALID, "BVH node %d is reachable twice (not a tree)", i);
             visited[i] = 1;
@@ -406,6 +430,12 @@ static int validate_scene(ptk_ctx* ctx) {
             int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
             int x = nv.xform(i);
             if (x >= n_xf) return bad(PTK_E_INVALID, "node %d: transform index %d out of range (%d)", i, x, n_xf);
+            if (x >= 0) {
+                // a mesh socket: at world level the traversal entry names the socket itself
+                if (in_mesh) wf_ok = false;
+                else { uint32_t e = 0x7F000000u | (uint32_t)i; memcpy(rt.data() + (size_t)i * 32 + 12, &e, 4); }
+            }
+            const bool child_in_mesh = in_mesh || x >= 0;
             if (idx <= 0) {
                 int base = std::abs(idx) - 1;
                 if (size > 0 && (base < 0 || base + size > n_ids)) return bad(PTK_E_INVALID, "leaf %d: object id slots from %d (count %d) outside the id buffer", i, base, size);
@@ -423,15 +453,21 @@ static int validate_scene(ptk_ctx* ctx) {
             int best = size;
             for (int l = 0; l < size; l++) {
                 int c = 0;
-                if (!need(idx + l, depth + 1, c)) return false;
+                if (!need(idx + l, depth + 1, child_in_mesh, c)) return false;
                 best = std::max(best, size - 1 + c);
             }
             out = best;
             return true;
         }
-    } walker{nv, idp, visited, n_nodes, n_ids, n_sph, n_tri, n_xf, walk_error, walk_code};
+    } walker{nv, idp, visited, n_nodes, n_ids, n_sph, n_tri, n_xf, walk_error, walk_code, rt_nodes, wf_ok};
     int result = 0;
-    if (!walker.need(0, 0, result)) return fail(ctx, walk_code, "%s", walk_error.c_str());
+    if (!walker.need(0, 0, false, result)) return fail(ctx, walk_code, "%s", walk_error.c_str());
+    if (n_nodes > 0x00FFFFFF) wf_ok = false;
+    ctx->wf_ok = wf_ok;
+    if (ctx->d_rt_nodes) { (void)hipFree(ctx->d_rt_nodes); ctx->d_rt_nodes = nullptr; }
+    // padded: the traversal kernel fetches all eight child slots of a node unconditionally
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_rt_nodes, rt_nodes.size() + 32 * PTK_MAX_WIDTH));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_rt_nodes, rt_nodes.data(), rt_nodes.size(), hipMemcpyHostToDevice, ctx->stream));
     ctx->stack_need = std::max(1, result + 1);
     if (ctx->stack_need > 1024)
         return fail(ctx, PTK_E_UNSUPPORTED, "BVH can need %d stack entries; the reference's traversal stack holds 1024", ctx->stack_need);
@@ -588,10 +624,107 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     }
 
     const int slot = (int)(ctx->dispatch_count % ptk_ctx::kTimingRing);
+
+    // Which schedule renders this dispatch.  The wavefront pipeline covers the plain render mode over
+    // the BVH; BVH/normal views, brute force, the early-t variant and traced dispatches use the
+    // one-kernel renderer.  Both give the same image.
+    const int fl = P.push.flags;
+    const int rb_max = std::max(P.push.max_refraction_bounces - 1, 0);
+    const int n_iter = P.push.max_default_depth + rb_max;  // most bounces any path can take (ray_tracer.comp:1572)
+    const bool wf_eligible = ctx->wf_ok && fl >= 0 && (fl & 1) && P.push.render_mode != 1 && P.push.render_mode != 2 &&
+                             !trace && !ctx->early_t_break && P.push.max_default_depth > 0 && n_iter <= PTK_WF_MAX_ITER;
+    if (ctx->renderer == PTK_RENDERER_WAVEFRONT && !wf_eligible)
+        return fail(ctx, PTK_E_UNSUPPORTED, "the wavefront renderer does not cover this dispatch (render mode, flags, tracing, early-t, depth > %d or nested mesh sockets)", PTK_WF_MAX_ITER);
+    const bool use_wf = wf_eligible && ctx->renderer != PTK_RENDERER_SINGLE_KERNEL;
+
+    if (!use_wf) {
+        ctx->wf_iters[slot] = 0;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
+        HIP_TRY(ctx, ptk_launch_render(&P, groups_x, groups_y, trace, ctx->early_t_break, lds_bytes, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
+        ctx->dispatch_count++;
+        return PTK_OK;
+    }
+
+    // queues and path state for groups_x * groups_y * 64 pixel slots
+    const size_t n_slots = lanes;
+    if (n_slots > ctx->wf_slots) {
+        if (ctx->d_wf) { (void)hipFree(ctx->d_wf); ctx->d_wf = nullptr; }
+        ctx->wf_slots = 0;
+        const size_t per_slot = 2 * 32 + 16 + 8 + 16 + 4 + 4 + 8 + 40;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_wf, n_slots * per_slot + 1024));
+        ctx->wf_slots = n_slots;
+    }
+    {
+        uint8_t* base = (uint8_t*)ctx->d_wf;
+        const size_t cap = ctx->wf_slots;
+        P.wf.counts = (uint32_t*)base;                       // counts then heads, zeroed per dispatch
+        P.wf.heads = P.wf.counts + (PTK_WF_MAX_ITER + 1);
+        base += 1024;
+        P.wf.rays[0] = (float4*)base; base += cap * 32;
+        P.wf.rays[1] = (float4*)base; base += cap * 32;
+        P.wf.hits = (int4*)base; base += cap * 16;
+        P.wf.color = (float4*)base; base += cap * 16;
+        P.wf.hit_uv = (float2*)base; base += cap * 8;
+        P.wf.misc = (int2*)base; base += cap * 8;
+        P.wf.seed = (float*)base; base += cap * 4;
+        P.wf.ior = (float*)base; base += cap * 4;
+        P.wf.inside = (int*)base;
+        P.wf.n_slots = (uint32_t)n_slots;
+        P.wf.tiles_x = groups_x;
+        P.wf.rt_nodes = ctx->d_rt_nodes;
+    }
+    // persistent traversal waves: as many as fit on the device at once
+    const size_t wf_lds = (size_t)(P.lds_cap + 1) * 64 * 4;  // one spare row for rejected children
+    int waves_per_cu = 0;
+    HIP_TRY(ctx, ptk_wavefront_occupancy(wf_lds, &waves_per_cu));
+    if (waves_per_cu <= 0) return fail(ctx, PTK_E_HIP, "the traversal kernel does not fit on a compute unit");
+    const int n_waves = (int)std::min<size_t>((size_t)waves_per_cu * std::max(ctx->n_cus, 1), (n_slots + 63) / 64);
+    P.spill = nullptr;
+    P.spill_t = nullptr;
+    P.spill_stride = (size_t)n_waves * 64;
+    if (spill_entries > 0) {
+        size_t ints = (size_t)spill_entries * n_waves * 64;
+        if (ints > ctx->wf_spill_ints) {
+            if (ctx->d_wf_spill) { (void)hipFree(ctx->d_wf_spill); ctx->d_wf_spill = nullptr; }
+            ctx->wf_spill_ints = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_wf_spill, ints * 4));
+            ctx->wf_spill_ints = ints;
+        }
+        P.spill = ctx->d_wf_spill;
+    }
+    if (!ctx->wf_ev[slot]) {
+        ctx->wf_ev[slot] = new hipEvent_t[2 * PTK_WF_MAX_ITER];
+        for (int k = 0; k < 2 * PTK_WF_MAX_ITER; k++) HIP_TRY(ctx, hipEventCreate(&ctx->wf_ev[slot][k]));
+    }
+    ctx->wf_iters[slot] = n_iter;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
-    HIP_TRY(ctx, ptk_launch_render(&P, groups_x, groups_y, trace, ctx->early_t_break, lds_bytes, ctx->stream));
+    HIP_TRY(ctx, ptk_launch_wavefront(&P, groups_x, groups_y, n_iter, wf_lds, n_waves, ctx->wf_ev[slot], ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
     ctx->dispatch_count++;
+    return PTK_OK;
+}
+
+int ptk_set_renderer(ptk_ctx* ctx, int renderer) {
+    if (!ctx) return PTK_E_INVALID;
+    if (renderer != PTK_RENDERER_AUTO && renderer != PTK_RENDERER_SINGLE_KERNEL && renderer != PTK_RENDERER_WAVEFRONT)
+        return fail(ctx, PTK_E_INVALID, "unknown renderer %d", renderer);
+    ctx->renderer = renderer;
+    return PTK_OK;
+}
+
+int ptk_dispatch_traverse_ms(ptk_ctx* ctx, int back, float* ms, int capacity, int* n_launches) {
+    if (!ctx || !n_launches || back < 0 || back >= ptk_ctx::kTimingRing) return PTK_E_INVALID;
+    if (ctx->dispatch_count <= back) return fail(ctx, PTK_E_STATE, "only %lld dispatches have run", ctx->dispatch_count);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int slot = (int)((ctx->dispatch_count - 1 - back) % ptk_ctx::kTimingRing);
+    const int n = ctx->wf_iters[slot];
+    *n_launches = n;
+    if (n > 0 && (!ms || capacity < n)) return fail(ctx, PTK_E_INVALID, "room for %d durations needed", n);
+    for (int k = 0; k < n; k++) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->wf_ev[slot][2 * k + 1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms[k], ctx->wf_ev[slot][2 * k], ctx->wf_ev[slot][2 * k + 1]));
+    }
     return PTK_OK;
 }
 

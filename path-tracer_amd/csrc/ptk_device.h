@@ -35,6 +35,26 @@ struct PtkTexDesc {
     int width, height;
 };
 
+// Wavefront renderer state: ray queues, hit records and per-pixel path state in HBM.
+// A queue entry is two float4: {origin.xyz, bits(pixel slot)}, {direction.xyz, 0}; the hit record of
+// entry i is hits[i] = {hit, object_id, transform_index, bits(t)} and hit_uv[i].
+#define PTK_WF_MAX_ITER 32
+struct PtkWavefront {
+    float4* rays[2];
+    int4* hits;
+    float2* hit_uv;
+    uint32_t* counts;  // counts[i] = rays queued for bounce i          (PTK_WF_MAX_ITER + 1 words)
+    uint32_t* heads;   // heads[i]  = rays of bounce i handed to waves  (PTK_WF_MAX_ITER + 1 words)
+    float4* color;     // path throughput, per pixel slot
+    float* seed;
+    float* ior;
+    int2* misc;        // {inside_of_count, refraction_bounces | inside-arrays-stored << 30}
+    int* inside;       // [10][n_slots]: in_mat[0..4], in_pri[0..4]
+    uint32_t n_slots;  // groups_x * groups_y * 64
+    int tiles_x;
+    const float4* rt_nodes;  // node buffer whose w words hold the traversal entry of each node
+};
+
 struct PtkParams {
     const float4* nodes;       // 2 float4 per 32-byte node
     const int* object_ids;
@@ -59,8 +79,14 @@ struct PtkParams {
     size_t spill_stride;  // lanes in the launch
     int* trace_primary;
     int* trace_counters;
+    PtkWavefront wf;
     PtkPush push;
 };
 
 extern "C" hipError_t ptk_launch_render(const PtkParams* p, int gx, int gy, int trace, int early_t,
                                         size_t lds_bytes, hipStream_t stream);
+// Wavefront renderer: generate, then n_iter x (traverse, shade).  ev[2k], ev[2k+1] (may be null) are
+// recorded around the k-th traversal launch.  n_waves = persistent traversal waves.
+extern "C" hipError_t ptk_launch_wavefront(const PtkParams* p, int gx, int gy, int n_iter, size_t lds_bytes,
+                                           int n_waves, hipEvent_t* ev, hipStream_t stream);
+extern "C" hipError_t ptk_wavefront_occupancy(size_t lds_bytes, int* waves_per_cu);

@@ -1,0 +1,832 @@
+// ptk_render_core.h -- device functions shared by the render kernels: ray/box/primitive tests,
+// BVH traversal, hit resolution, textures, nested dielectrics and the bounce, each following the
+// operation order of shaders/ray_tracer.comp (line numbers cited per function).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ptk_device.h"
+#include "ptk_math.h"
+
+namespace {
+
+constexpr int IS_SPHERE = 1;   // ray_tracer.comp:127-130
+constexpr int IS_PLANE = 2;
+constexpr int IS_TRIANGLE = 3;
+constexpr int TEX_IS_SAMPLED = 1;  // :133-134
+constexpr int TEX_IS_SPATIAL = 2;
+constexpr int MAX_OVERLAP = 5;     // :156
+constexpr int32_t INT_NEG_LIMIT = (int32_t)0x80000000u;
+constexpr uint32_t SOCKET_MARK = 0x7F000000u;  // stack entry: mesh socket, low 24 bits = its node index
+#define PT_INF (__builtin_inff())
+
+struct Ray {
+    f3 o;
+    float start;
+    f3 d;
+    float end;
+};
+
+struct Hit {
+    int hit;
+    int object_id;
+    int transform_index;
+    float u, v;
+};
+
+struct Lane {
+    // shader globals that persist over the path (:159-237)
+    float current_IOR;
+    int inside_of_count;
+    int in_mat[MAX_OVERLAP];
+    int in_pri[MAX_OVERLAP];
+    int is_emissive;
+    int refraction_bounces;
+    int ignore_attenuation;
+    float seed;
+    int node_hit_count, object_hit_count;
+};
+
+PTK_DEV int bfe_i(int v, int off, int bits) { return ((int)((uint32_t)v << (32 - off - bits))) >> (32 - bits); }
+PTK_DEV int iabs(int v) { return v < 0 ? -v : v; }
+PTK_DEV bool in_range(float value, float start, float end) { return start <= value && end >= value; }  // :548-551
+
+// ---- random (:464-507) -----------------------------------------------------
+PTK_DEV float pt_rand(float seed) { return pfract((seed * 23489.52364f) / 0.0836f); }
+PTK_DEV float noise(Lane& L) {
+    float s = L.seed;
+    L.seed = L.seed + 1.0f;
+    return pfract(psin(s) * 43758.5453123f);
+}
+PTK_DEV float pcg(Lane& L) {
+    float s = L.seed;
+    L.seed = L.seed + 1.0f;
+    uint32_t state = fbits(s) * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (float)((word >> 22u) ^ word) / 4294967295.0f;
+}
+PTK_DEV f3 random_point_on_sphere(Lane& L) {
+    float theta1 = pcg(L) * (3.1415926535897932385f * 2.0f);
+    float theta2 = pacos(2.0f * pcg(L) - 1.0f);
+    float s1, c1, s2, c2;
+    psincos(theta1, s1, c1);
+    psincos(theta2, s2, c2);
+    return mk3(c1 * s2, c2, s1 * s2);
+}
+PTK_DEV float hash3(float x, float y, float z) {
+    uint32_t px = fbits(x), py = fbits(y), pz = fbits(z);
+    uint32_t qx = 1103515245u * ((px >> 1u) ^ py);
+    uint32_t qy = 1103515245u * ((py >> 1u) ^ pz);
+    uint32_t qz = 1103515245u * ((pz >> 1u) ^ px);
+    uint32_t h32 = 1103515245u * ((qx ^ qz) ^ (qy >> 3u));
+    uint32_t n = h32 ^ (h32 >> 16u);
+    return (float)n * (1.0f / 2147483648.0f);
+}
+
+// ---- small helpers ------------------------------------------------------------
+PTK_DEV float offset_axis(float p, float n) {  // :532-546
+    int32_t off = pf2i(n * 256.0f);
+    int32_t bits = (int32_t)(fbits(p) + (uint32_t)((p < 0.0f) ? -off : off));
+    float p_int = bitsf((uint32_t)bits);
+    return (pabs(p) < (1.0f / 32.0f)) ? (p + (1.0f / 65536.0f) * n) : p_int;
+}
+PTK_DEV f3 offset_ray(f3 point, f3 normal) {
+    return mk3(offset_axis(point.x, normal.x), offset_axis(point.y, normal.y), offset_axis(point.z, normal.z));
+}
+PTK_DEV Ray new_ray(f3 origin, f3 direction) {  // :444-446
+    Ray r;
+    r.o = origin;
+    r.start = 0.0f;
+    r.d = normalize3(direction);
+    r.end = PT_INF;
+    return r;
+}
+PTK_DEV bool near_zero1(float f) { return pabs(f) < 1e-6f; }
+PTK_DEV bool near_zero3(f3 v) { return pabs(v.x) < 1e-6f && pabs(v.y) < 1e-6f && pabs(v.z) < 1e-6f; }
+PTK_DEV float reflectance(float eta, float cos_theta) {  // :456-461
+    float r0 = (1.0f - eta) / (1.0f + eta);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * ppow(1.0f - cos_theta, 5.0f);
+}
+PTK_DEV m44 load_xform(const PtkParams& P, int i) {
+    m44 m;
+    const float4* p = P.transforms + (size_t)i * 4;
+    m.c0 = p[0]; m.c1 = p[1]; m.c2 = p[2]; m.c3 = p[3];
+    return m;
+}
+
+// slab test, :670-689.  The swap is the shader's arithmetic swap (a=a+b; b=a-b; a=a-b).
+PTK_DEV float hit_aabb(float4 bmin, float4 bmax, f3 o, f3 inv, int neg_mask, float start, float end) {
+    float t0, t1;
+#define PTK_SLAB(MINV, MAXV, O, INV, BIT)                         \
+    t0 = ((MINV) - (O)) * (INV);                                  \
+    t1 = ((MAXV) - (O)) * (INV);                                  \
+    if (neg_mask & (BIT)) { t0 = t0 + t1; t1 = t0 - t1; t0 = t0 - t1; } \
+    if (t0 > start) start = t0;                                   \
+    if (t1 < end) end = t1;                                       \
+    if (end <= start) return -1.0f;
+    PTK_SLAB(bmin.x, bmax.x, o.x, inv.x, 1)
+    PTK_SLAB(bmin.y, bmax.y, o.y, inv.y, 2)
+    PTK_SLAB(bmin.z, bmax.z, o.z, inv.z, 4)
+#undef PTK_SLAB
+    return start;
+}
+
+template <bool TRACE>
+PTK_DEV void hit_sphere_gems(const PtkParams& P, Ray& ray, Hit& h, int object_id, int cur_xf, int* cnt) {  // :803-841
+    float4 s = P.spheres[(size_t)bfe_i(object_id, 0, 24) * 2];
+    if (TRACE) cnt[PTK_CNT_SPHERE_TESTS]++;
+    f3 oc = ray.o - ld3(s);
+    float half_b = dot3(-oc, ray.d);
+    float r_sqrd = s.w * s.w;
+    f3 temp = oc + ray.d * half_b;
+    float discriminant = r_sqrd - dot3(temp, temp);
+    if (discriminant < 0.0f) return;
+    float c = dot3(oc, oc) - r_sqrd;
+    float sqrtd = psqrt(discriminant);
+    float q = half_b + psign(half_b) * sqrtd;
+    float root = c / q;
+    if (!in_range(root, ray.start, ray.end)) {
+        root = q;
+        if (!in_range(root, ray.start, ray.end)) return;
+    }
+    h.hit = 1; h.object_id = object_id; h.transform_index = cur_xf;
+    ray.end = root;
+}
+
+PTK_DEV void hit_sphere_plain(const PtkParams& P, Ray& ray, Hit& h, int object_id, int cur_xf) {  // :691-727
+    float4 s = P.spheres[(size_t)bfe_i(object_id, 0, 24) * 2];
+    f3 oc = ray.o - ld3(s);
+    float a = dot3(ray.d, ray.d);
+    float half_b = dot3(oc, ray.d);
+    float c = dot3(oc, oc) - s.w * s.w;
+    float discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0f) return;
+    float sqrtd = psqrt(discriminant);
+    float root = (-half_b - sqrtd) / a;
+    if (!in_range(root, ray.start, ray.end)) {
+        root = (-half_b + sqrtd) / a;
+        if (!in_range(root, ray.start, ray.end)) return;
+    }
+    h.hit = 1; h.object_id = object_id; h.transform_index = cur_xf;
+    ray.end = root;
+}
+
+template <bool TRACE>
+PTK_DEV void hit_triangle_mt(const PtkParams& P, Ray& ray, Hit& h, int object_id, int cur_xf, int* cnt) {  // :926-969
+    const float4* t = P.triangles + (size_t)bfe_i(object_id, 0, 24) * 5;
+    if (TRACE) cnt[PTK_CNT_TRI_TESTS]++;
+    f3 A = ld3(t[0]), B = ld3(t[1]), C = ld3(t[2]);
+    f3 E1 = B - A, E2 = C - A;
+    f3 N = cross3(E1, E2);
+    float det = -dot3(ray.d, N);
+    if (near_zero1(det)) return;
+    float invdet = 1.0f / det;
+    f3 AO = ray.o - A;
+    float tt = dot3(AO, N) * invdet;
+    if (!in_range(tt, ray.start, ray.end)) return;
+    f3 DAO = cross3(AO, ray.d);
+    float u = dot3(E2, DAO) * invdet;
+    float v = -dot3(E1, DAO) * invdet;
+    if (u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f) {
+        h.hit = 1; h.object_id = object_id; h.transform_index = cur_xf;
+        h.u = u; h.v = v;
+        ray.end = tt;
+    }
+}
+
+PTK_DEV void hit_plane(const PtkParams& P, Ray& ray, Hit& h, int index, int cur_xf) {  // :851-875
+    float4 pl = P.planes[(size_t)index * 2];
+    f3 n = ld3(pl);
+    float t = (pl.w - dot3(ray.o, n)) / dot3(n, ray.d);
+    if (t != t || pabs(t) == PT_INF) return;
+    if (!in_range(t, ray.start, ray.end)) return;
+    h.hit = 1; h.object_id = index + (IS_PLANE << 24); h.transform_index = cur_xf;
+    ray.end = t;
+}
+
+template <bool TRACE>
+PTK_DEV void hit_object(const PtkParams& P, Lane& L, Ray& ray, Hit& h, int object_id, int cur_xf, int* cnt) {  // :979-996
+    int type = bfe_i(object_id, 24, 8);
+    L.object_hit_count++;
+    if (type == IS_SPHERE) hit_sphere_gems<TRACE>(P, ray, h, object_id, cur_xf, cnt);
+    else if (type == IS_TRIANGLE) hit_triangle_mt<TRACE>(P, ray, h, object_id, cur_xf, cnt);
+}
+
+// ---- traversal stack ------------------------------------------------------------
+struct Stack {
+    int* lds;        // this wave's LDS window, [entry][lane]
+    int* spill;      // global column of this lane, stride = spill_stride ints
+    size_t spill_stride;
+    int lds_cap;
+    int lane;
+};
+PTK_DEV void st_write(const Stack& s, int i, int v) {
+    if (i < s.lds_cap) s.lds[i * 64 + s.lane] = v;
+    else s.spill[(size_t)(i - s.lds_cap) * s.spill_stride] = v;
+}
+PTK_DEV int st_read(const Stack& s, int i) {
+    if (i < s.lds_cap) return s.lds[i * 64 + s.lane];
+    return s.spill[(size_t)(i - s.lds_cap) * s.spill_stride];
+}
+
+// Closest hit over planes + BVH, :1200-1320 with :1115-1198 folded into one loop.
+template <bool TRACE, bool EARLY_T>
+PTK_DEV Hit check_ray_hit_bvh(const PtkParams& P, Lane& L, Ray& ray, const Stack& S, const Stack& ST, int* cnt) {
+    Hit h;
+    h.hit = 0; h.object_id = 0; h.transform_index = -1; h.u = 0.0f; h.v = 0.0f;
+
+    // planes are tested first, outside the BVH (:1204).  Records whose normal is
+    // exactly zero always yield NaN or Inf and are rejected at :859, so only the
+    // others are listed in live_planes (ascending index).
+    for (int i = 0; i < P.n_live_planes; ++i) hit_plane(P, ray, h, P.live_planes[i], -1);
+
+    f3 inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    int neg = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
+
+    float4 rmin = P.nodes[0], rmax = P.nodes[1];
+    L.node_hit_count++;
+    float root_hit = hit_aabb(rmin, rmax, ray.o, inv, neg, ray.start, ray.end);
+    int sp = 0;
+    if (in_range(root_hit, ray.start, ray.end)) {
+        int xf0 = (int)fbits(rmax.w);
+        st_write(S, 0, xf0 >= 0 ? (int)(SOCKET_MARK | 0u) : (int)fbits(rmin.w));
+        if (EARLY_T) st_write(ST, 0, (int)fbits(root_hit));
+        sp = 1;
+    }
+
+    // state of an instanced (mesh-socket) sub-traversal, :1286-1313
+    bool in_mesh = false;
+    int sub_base = 0;
+    int cur_xf = -1;
+    Ray wray = ray;        // saved world ray while in_mesh
+    f3 winv = inv;
+    int wneg = neg;
+    float dir_len = 1.0f;
+
+    for (;;) {
+        if (in_mesh && sp <= sub_base) {
+            // check_ray_hit_BVH_mesh returned: map the local end back (:1309-1310)
+            float local_end = ray.end;
+            ray = wray; inv = winv; neg = wneg;
+            ray.end = local_end / dir_len;
+            in_mesh = false;
+            cur_xf = -1;
+        }
+        if (sp <= 0) break;
+        --sp;
+        int entry = st_read(S, sp);
+        if (EARLY_T) {
+            float te = bitsf((uint32_t)st_read(ST, sp));
+            if (!in_range(te, ray.start, ray.end)) {
+                if (in_mesh) continue;  // calculate_top_node returns (:1128-1132)
+                break;                  // world loop breaks (:1280-1284)
+            }
+        }
+        int node_index, node_size;
+        if (((uint32_t)entry & 0xFF000000u) == SOCKET_MARK) {
+            int self = entry & 0x00FFFFFF;
+            float4 smin = P.nodes[(size_t)self * 2], smax = P.nodes[(size_t)self * 2 + 1];
+            int node_id = (int)fbits(smin.w);
+            node_index = bfe_i(node_id, 0, 24);
+            node_size = iabs(bfe_i(node_id, 24, 8));
+            if (!in_mesh) {
+                int xf = (int)fbits(smax.w);
+                m44 M = load_xform(P, xf);
+                if (TRACE) cnt[PTK_CNT_SOCKETS]++;
+                wray = ray; winv = inv; wneg = neg;
+                f3 unnorm = mul_mv(M, ray.d, 0.0f);
+                dir_len = length3(unnorm);
+                Ray nr;
+                nr.d = div3(unnorm, dir_len);
+                nr.o = mul_mv(M, ray.o, 1.0f);
+                nr.end = ray.end * dir_len;
+                nr.start = ray.start * dir_len;
+                float4 cmin = P.nodes[(size_t)node_index * 2];
+                if (EARLY_T) {
+                    float4 cmax = P.nodes[(size_t)node_index * 2 + 1];
+                    L.node_hit_count++;
+                    float aabb_t = hit_aabb(cmin, cmax, ray.o, inv, neg, ray.start, ray.end);
+                    st_write(ST, sp, (int)fbits(aabb_t));
+                }
+                sub_base = sp;
+                st_write(S, sp, (int)fbits(cmin.w));
+                sp++;
+                cur_xf = xf;
+                ray = nr;
+                inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+                neg = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
+                in_mesh = true;
+                continue;
+            }
+            // inside a mesh sub-traversal sockets are ordinary nodes (:1115-1181)
+        } else {
+            node_index = bfe_i(entry, 0, 24);
+            node_size = iabs(bfe_i(entry, 24, 8));
+        }
+
+        if (node_index <= 0) {
+            // leaf: test its objects in order (:1137-1142)
+            int base = iabs(node_index) - 1;
+            for (int k = 0; k < node_size; k++) {
+                hit_object<TRACE>(P, L, ray, h, P.object_ids[base + k], cur_xf, cnt);
+            }
+            continue;
+        }
+
+        // inner: slab-test the children, then push them nearest-on-top (:1144-1180)
+        float ts[PTK_MAX_WIDTH];
+        int es[PTK_MAX_WIDTH];
+        int added = 0;
+#pragma unroll
+        for (int l = 0; l < PTK_MAX_WIDTH; l++) {
+            ts[l] = PT_INF;
+            es[l] = 0;
+            if (l < node_size) {
+                float4 cmin = P.nodes[(size_t)(node_index + l) * 2];
+                float4 cmax = P.nodes[(size_t)(node_index + l) * 2 + 1];
+                L.node_hit_count++;
+                float t = hit_aabb(cmin, cmax, ray.o, inv, neg, ray.start, ray.end);
+                if (in_range(t, ray.start, ray.end)) {
+                    ts[l] = t;
+                    int cxf = (int)fbits(cmax.w);
+                    es[l] = (!in_mesh && cxf >= 0) ? (int)(SOCKET_MARK | (uint32_t)(node_index + l)) : (int)fbits(cmin.w);
+                    added++;
+                }
+            }
+        }
+        // rank = number of accepted children that the shader's selection loop
+        // would pick earlier: smaller t, or equal t in a lower slot.
+#pragma unroll
+        for (int l = 0; l < PTK_MAX_WIDTH; l++) {
+            if (ts[l] < PT_INF) {
+                int rank = 0;
+#pragma unroll
+                for (int j = 0; j < PTK_MAX_WIDTH; j++) {
+                    if (j < l) rank += (ts[j] <= ts[l]) ? 1 : 0;
+                    else if (j > l) rank += (ts[j] < ts[l]) ? 1 : 0;
+                }
+                int pos = sp + added - 1 - rank;
+                st_write(S, pos, es[l]);
+                if (EARLY_T) st_write(ST, pos, (int)fbits(ts[l]));
+            }
+        }
+        sp += added;
+    }
+    return h;
+}
+
+// ---- phase-coherent traversal ------------------------------------------------------------------
+// Same per-lane order of node pops, box tests and object tests as the loop above, but the wave only
+// runs one kind of step at a time: in every round the lanes whose next node is an inner node (or a
+// mesh socket) and the lanes whose next node is a leaf are counted by ballot, and the larger group
+// advances while the other waits.  A lane's own sequence is untouched, so results are identical; the
+// wave no longer pays the inner-node code and the leaf code in every iteration.  The next node to
+// visit stays in a register (`cur`): the nearest accepted child is not pushed and popped again.
+#ifndef PTK_VOTE_INNER
+#define PTK_VOTE_INNER(ni, nl) ((ni) >= (nl))
+#endif
+constexpr uint32_t ENTRY_NONE = 0x7E000000u;  // "inner node with 126 children": never a real entry
+
+// slab test without early returns; same value as hit_aabb (a failed axis makes the result -1).
+PTK_DEV float hit_aabb_bl(float4 bmin, float4 bmax, f3 o, f3 inv, int neg_mask, float start, float end) {
+    float t0, t1;
+    bool fail = false;
+#define PTK_SLAB2(MINV, MAXV, O, INV, BIT)                                         \
+    t0 = ((MINV) - (O)) * (INV);                                                   \
+    t1 = ((MAXV) - (O)) * (INV);                                                   \
+    {                                                                              \
+        float a_ = t0 + t1, b_ = a_ - t1, c_ = a_ - b_;                            \
+        bool n_ = (neg_mask & (BIT)) != 0;                                         \
+        t0 = n_ ? c_ : t0;                                                         \
+        t1 = n_ ? b_ : t1;                                                         \
+    }                                                                              \
+    start = (t0 > start) ? t0 : start;                                             \
+    end = (t1 < end) ? t1 : end;                                                   \
+    fail = fail || (end <= start);
+    PTK_SLAB2(bmin.x, bmax.x, o.x, inv.x, 1)
+    PTK_SLAB2(bmin.y, bmax.y, o.y, inv.y, 2)
+    PTK_SLAB2(bmin.z, bmax.z, o.z, inv.z, 4)
+#undef PTK_SLAB2
+    return fail ? -1.0f : start;
+}
+
+template <bool TRACE>
+PTK_DEV Hit check_ray_hit_bvh2(const PtkParams& P, Lane& L, Ray& ray, const Stack& S, int* cnt) {
+    Hit h;
+    h.hit = 0; h.object_id = 0; h.transform_index = -1; h.u = 0.0f; h.v = 0.0f;
+    for (int i = 0; i < P.n_live_planes; ++i) hit_plane(P, ray, h, P.live_planes[i], -1);
+
+    f3 inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    int neg = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
+
+    uint32_t cur = ENTRY_NONE;
+    int sp = 0;
+    {
+        float4 rmin = P.nodes[0], rmax = P.nodes[1];
+        L.node_hit_count++;
+        float root_hit = hit_aabb_bl(rmin, rmax, ray.o, inv, neg, ray.start, ray.end);
+        if (in_range(root_hit, ray.start, ray.end)) cur = ((int)fbits(rmax.w) >= 0) ? SOCKET_MARK : fbits(rmin.w);
+    }
+    bool in_mesh = false;
+    int sub_base = 0;
+    int cur_xf = -1;
+    f3 w_o = ray.o, w_d = ray.d;  // world ray while inside a mesh
+    float w_start = ray.start;
+    float dir_len = 1.0f;
+
+    for (;;) {
+        const bool has = cur != ENTRY_NONE;
+        const bool is_leaf = has && ((int)cur <= 0);
+        const bool is_inner = has && !is_leaf;
+        const unsigned long long mi = __ballot(is_inner), ml = __ballot(is_leaf);
+        if ((mi | ml) == 0ull) break;
+        bool refill = false;
+#ifdef PTK_ROUND_STATS
+        if (TRACE) { cnt[PTK_CNT_HIT_SPHERE]++; if (PTK_VOTE_INNER(__popcll(mi), __popcll(ml))) { if (is_inner) cnt[PTK_CNT_SPHERE_TESTS]++; } else { cnt[PTK_CNT_SOCKETS]++; if (is_leaf) cnt[PTK_CNT_HIT_PLANE]++; } }
+#endif
+        if (PTK_VOTE_INNER(__popcll(mi), __popcll(ml))) {
+            if (is_inner) {
+                if ((cur & 0xFF000000u) == SOCKET_MARK) {
+                    // world level: enter the mesh (:1286-1313); its root is the next node
+                    int self = (int)(cur & 0x00FFFFFFu);
+                    float4 smin = P.nodes[(size_t)self * 2], smax = P.nodes[(size_t)self * 2 + 1];
+                    int node_index = bfe_i((int)fbits(smin.w), 0, 24);
+                    int xf = (int)fbits(smax.w);
+                    m44 M = load_xform(P, xf);
+                    if (TRACE) cnt[PTK_CNT_SOCKETS]++;
+                    w_o = ray.o; w_d = ray.d; w_start = ray.start;
+                    f3 unnorm = mul_mv(M, ray.d, 0.0f);
+                    dir_len = length3(unnorm);
+                    f3 no = mul_mv(M, ray.o, 1.0f);
+                    ray.d = div3(unnorm, dir_len);
+                    ray.o = no;
+                    ray.end = ray.end * dir_len;
+                    ray.start = ray.start * dir_len;
+                    inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+                    neg = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
+                    sub_base = sp;
+                    cur_xf = xf;
+                    in_mesh = true;
+                    cur = fbits(P.nodes[(size_t)node_index * 2].w);
+                } else {
+                    const int node_index = bfe_i((int)cur, 0, 24);
+                    const int node_size = iabs(bfe_i((int)cur, 24, 8));
+                    float ts[PTK_MAX_WIDTH];
+                    uint32_t es[PTK_MAX_WIDTH];
+                    int added = 0;
+#pragma unroll
+                    for (int l = 0; l < PTK_MAX_WIDTH; l++) {
+                        const bool v = l < node_size;
+                        const size_t ci = (size_t)(node_index + (v ? l : 0)) * 2;
+                        const float4 cmin = P.nodes[ci];
+                        const float4 cmax = P.nodes[ci + 1];
+                        const float t = hit_aabb_bl(cmin, cmax, ray.o, inv, neg, ray.start, ray.end);
+                        const bool acc = v && in_range(t, ray.start, ray.end);
+                        ts[l] = acc ? t : PT_INF;
+                        const bool sock = !in_mesh && ((int)fbits(cmax.w) >= 0);
+                        es[l] = sock ? (SOCKET_MARK | (uint32_t)(node_index + l)) : fbits(cmin.w);
+                        added += acc ? 1 : 0;
+                        L.node_hit_count += v ? 1 : 0;
+                    }
+                    // rank r goes to stack slot sp + added - 1 - r; rank 0 (nearest) stays in `cur`
+                    cur = ENTRY_NONE;
+#pragma unroll
+                    for (int l = 0; l < PTK_MAX_WIDTH; l++) {
+                        int rank = 0;
+#pragma unroll
+                        for (int j = 0; j < PTK_MAX_WIDTH; j++) {
+                            if (j < l) rank += (ts[j] <= ts[l]) ? 1 : 0;
+                            else if (j > l) rank += (ts[j] < ts[l]) ? 1 : 0;
+                        }
+                        if (ts[l] < PT_INF) {
+                            if (rank == 0) cur = es[l];
+                            else st_write(S, sp + added - 1 - rank, (int)es[l]);
+                        }
+                    }
+                    sp += (added > 0) ? added - 1 : 0;
+                    refill = added == 0;
+                }
+            }
+        } else {
+            if (is_leaf) {
+                const int node_index = bfe_i((int)cur, 0, 24);
+                const int node_size = iabs(bfe_i((int)cur, 24, 8));
+                const int base = iabs(node_index) - 1;
+                for (int k = 0; k < node_size; k++) {
+                    hit_object<TRACE>(P, L, ray, h, P.object_ids[base + k], cur_xf, cnt);
+                }
+                refill = true;
+            }
+        }
+        if (refill) {
+            // next node of this lane: pop; an empty mesh sub-stack first maps the ray back (:1309-1310)
+            cur = ENTRY_NONE;
+            if (in_mesh && sp <= sub_base) {
+                float local_end = ray.end;
+                ray.o = w_o; ray.d = w_d; ray.start = w_start;
+                ray.end = local_end / dir_len;
+                inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+                neg = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
+                in_mesh = false;
+                cur_xf = -1;
+            }
+            if (sp > 0) cur = (uint32_t)st_read(S, --sp);
+        }
+    }
+    return h;
+}
+
+// Brute-force closest hit when USE_BVH is off, :1093-1101.
+template <bool TRACE>
+PTK_DEV Hit check_ray_hit_all(const PtkParams& P, Ray& ray, int* cnt) {
+    Hit h;
+    h.hit = 0; h.object_id = 0; h.transform_index = -1; h.u = 0.0f; h.v = 0.0f;
+    for (int i = 0; i < P.n_spheres; ++i) hit_sphere_plain(P, ray, h, i + (IS_SPHERE << 24), -1);
+    for (int i = 0; i < P.n_triangles; ++i) hit_triangle_mt<TRACE>(P, ray, h, i + (IS_TRIANGLE << 24), -1, cnt);
+    for (int i = 0; i < P.n_planes; ++i) hit_plane(P, ray, h, i, -1);
+    return h;
+}
+
+// ---- hit resolution (:1003-1091) ----------------------------------------------------
+struct Surf {
+    f3 point;
+    f3 normal;
+    float u, v;
+    int mtl_index;
+    uint32_t texture_id;
+    f3 albedo;
+    int dielectric_priority;
+};
+
+PTK_DEV void sphere_get_uv(f3 pos, float& u, float& v) {  // :620-627
+    float theta = pacos(pos.y);
+    float phi = patan2(-pos.z, pos.x) + 3.1415926535897932385f;
+    u = phi / (3.1415926535897932385f * 2.0f);
+    v = theta / 3.1415926535897932385f;
+}
+
+template <bool TRACE>
+PTK_DEV Surf determine_rayhit(const PtkParams& P, Lane& L, const Ray& ray_in, const Hit& h, int* cnt) {
+    Surf s;
+    int type = bfe_i(h.object_id, 24, 8);
+    int index = bfe_i(h.object_id, 0, 24);
+    s.u = h.u; s.v = h.v;
+    s.point = mk3(0, 0, 0); s.normal = mk3(0, 0, 0); s.mtl_index = 0; s.texture_id = 0;
+    if (type == IS_SPHERE) {
+        float4 a = P.spheres[(size_t)index * 2], b = P.spheres[(size_t)index * 2 + 1];
+        f3 center = ld3(a);
+        s.mtl_index = (int)fbits(b.x);
+        s.texture_id = fbits(b.y);
+        bool need_uv = (s.texture_id >> 30) != 0u || (s.texture_id & 0x3fffffffu) != 0u;
+        if (h.transform_index >= 0) {
+            m44 m = load_xform(P, h.transform_index);
+            m44 matrix = inverse44(m);
+            f3 td = mul_mv(m, ray_in.d, 0.0f);
+            f3 to = mul_mv(m, ray_in.o, 1.0f);
+            f3 usn = normalize3((to + td * ray_in.end) - center);
+            if (need_uv) sphere_get_uv(usn, s.u, s.v);
+            s.point = center + usn * a.w;
+            s.point = mul_mv(matrix, s.point, 1.0f);
+            s.normal = normalize3(mul_vm(usn, 0.0f, m));
+        } else {
+            s.normal = normalize3((ray_in.o + ray_in.d * ray_in.end) - center);
+            if (need_uv) sphere_get_uv(s.normal, s.u, s.v);
+            s.point = center + s.normal * a.w;
+        }
+        if (TRACE) cnt[PTK_CNT_HIT_SPHERE]++;
+    } else if (type == IS_PLANE) {
+        float4 a = P.planes[(size_t)index * 2], b = P.planes[(size_t)index * 2 + 1];
+        s.point = ray_in.o + ray_in.d * ray_in.end;
+        s.mtl_index = (int)fbits(b.x);
+        s.texture_id = fbits(b.y);
+        s.normal = ld3(a);
+        if (TRACE) cnt[PTK_CNT_HIT_PLANE]++;
+    } else if (type == IS_TRIANGLE) {
+        const float4* t = P.triangles + (size_t)index * 5;
+        f3 p1 = ld3(t[0]), p2 = ld3(t[1]), p3 = ld3(t[2]);
+        float4 pr = t[4];
+        s.mtl_index = (int)fbits(pr.x);
+        s.texture_id = fbits(pr.y);
+        s.normal = normalize3(cross3(p1 - p3, p1 - p2));
+        float w = (1.0f - h.u) - h.v;
+        s.point = (p2 * h.u + p3 * h.v) + p1 * w;
+        if (h.transform_index >= 0) {
+            m44 m = load_xform(P, h.transform_index);
+            m44 matrix = inverse44(m);
+            s.normal = normalize3(mul_vm(s.normal, 0.0f, m));
+            s.point = mul_mv(matrix, s.point, 1.0f);
+        }
+        if (dot3(s.normal, ray_in.d) > 0.0f) s.normal = s.normal * -1.0f;
+        if (TRACE) cnt[PTK_CNT_HIT_TRIANGLE]++;
+    }
+    const float4* mt = P.materials + (size_t)s.mtl_index * 4;
+    float4 m0 = mt[0];
+    float4 m2 = mt[2];
+    s.albedo = ld3(m0);
+    s.dielectric_priority = (int)fbits(m2.x);
+    if (P.use_emission) L.is_emissive = ((int)fbits(m2.y)) != 0;
+    if (TRACE) cnt[PTK_CNT_MATERIAL_FETCH]++;
+    return s;
+}
+
+// ---- textures (:632-659) ------------------------------------------------------------
+PTK_DEV float4 checker(float sum) {
+    return (pmod(sum, 2.0f) != 0.0f) ? make_float4(0.9f, 0.9f, 0.9f, 1.0f) : make_float4(0.2f, 0.3f, 0.1f, 1.0f);
+}
+PTK_DEV float4 get_texture(const PtkParams& P, const Surf& s) {
+    uint32_t type = s.texture_id >> 30;
+    uint32_t index = s.texture_id & 0x3fffffffu;
+    if (type & TEX_IS_SAMPLED) {
+        // texture() with Godot's default sampler: nearest, clamp to edge, level 0
+        const float* rgba = nullptr;
+        int w = 8, hgt = 8;
+        if (index < (uint32_t)P.n_textures) { rgba = P.textures[index].rgba; w = P.textures[index].width; hgt = P.textures[index].height; }
+        int i = pf2i(floorf(s.u * (float)w)), j = pf2i(floorf(s.v * (float)hgt));
+        i = i < 0 ? 0 : (i > w - 1 ? w - 1 : i);
+        j = j < 0 ? 0 : (j > hgt - 1 ? hgt - 1 : j);
+        if (rgba == nullptr) {  // 8x8 pink/black filler grid (pt_utils.gd:122-137)
+            bool pink = (((j % 2) + (i % 2)) % 2) == 0;
+            return pink ? make_float4(56.0f / 255.0f, 16.0f / 255.0f, 56.0f / 255.0f, 56.0f / 255.0f)
+                        : make_float4(0.0f, 0.0f, 0.0f, 56.0f / 255.0f);
+        }
+        const float* p = rgba + ((size_t)j * w + i) * 4;
+        return make_float4(p[0], p[1], p[2], p[3]);
+    }
+    if (index == 0) return make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    f3 pos = (type & TEX_IS_SPATIAL) ? s.point : mk3(s.u, s.v, 0.0f);
+    if (index <= (uint32_t)P.n_proc) {
+        int b = P.proc_builtin[index - 1];
+        if (b == PTK_PROC_CHECKER_BOARD) {  // procedural_textures/checker_board.comp
+            return checker(floorf(pos.x * 2.0f) + floorf(pos.z * 2.0f));
+        }
+        if (b == PTK_PROC_CHECKER_BOARD_SPATIAL) {  // procedural_textures/checker_board_spatial.comp
+            return checker((floorf(pos.x * 2.0f) + floorf(pos.y * 2.0f)) + floorf(pos.z * 2.0f));
+        }
+    }
+    return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// ---- nested dielectrics (:1369-1419) ----------------------------------------------------
+PTK_DEV void add_material_to_inside_of(Lane& L, int material_index, int priority) {
+    int shift = 1, insert_index = 0;
+#pragma unroll
+    for (int i = MAX_OVERLAP - 1; i > 0; i--) {
+        if (priority < L.in_pri[i - 1] && shift == 1) { insert_index = i; shift = 0; }
+        int src = i - shift;
+        int m = L.in_mat[i], p = L.in_pri[i];
+        if (src == i - 1) { m = L.in_mat[i - 1]; p = L.in_pri[i - 1]; }
+        L.in_mat[i] = m; L.in_pri[i] = p;
+    }
+#pragma unroll
+    for (int i = 0; i < MAX_OVERLAP; i++) {
+        if (i == insert_index) { L.in_mat[i] = material_index; L.in_pri[i] = priority; }
+    }
+    L.inside_of_count++;
+}
+PTK_DEV void remove_material_from_inside_of(Lane& L, int material_index) {
+    int shift = 0;
+#pragma unroll
+    for (int i = 0; i < MAX_OVERLAP - 1; i++) {
+        if (shift == 0 && material_index == L.in_mat[i]) shift = 1;
+        if (shift) { L.in_mat[i] = L.in_mat[i + 1]; L.in_pri[i] = L.in_pri[i + 1]; }
+    }
+    L.in_mat[MAX_OVERLAP - 1] = 0;
+    L.in_pri[MAX_OVERLAP - 1] = INT_NEG_LIMIT;
+    L.inside_of_count--;
+}
+PTK_DEV int material_chooser(const Lane& L, bool is_inside, float dielectric_priority, int object_material) {
+    int mx = L.in_mat[0], my = L.in_mat[1];
+    bool same_first = mx == object_material;
+    bool same_second = my == object_material;
+    bool old_higher = dielectric_priority < (float)L.in_pri[0];
+    if (is_inside && same_first && !same_second) return my;
+    if (is_inside || same_first || old_higher) return mx;
+    return object_material;
+}
+
+// ---- bounce (:1324-1359, :1422-1549) ----------------------------------------------------
+PTK_DEV Ray bounce_ray(const PtkParams& P, Lane& L, const Ray& ray_in, Surf& s) {
+    bool is_inside = dot3(s.normal, ray_in.d) > 0.0f;
+    f3 normal = is_inside ? -s.normal : s.normal;
+    int material = s.mtl_index;
+    float eta_in, eta_out;
+    float4 om0, om1;  // the material that decides the branch: albedo/roughness, metallic/opacity/reflectivity/IOR
+    if (P.refraction_mode == 0) {
+        om1 = P.materials[(size_t)s.mtl_index * 4 + 1];
+        float material_ior = om1.w;
+        eta_in = is_inside ? material_ior : 1.0f;
+        eta_out = is_inside ? 1.0f : material_ior;
+    } else if (P.refraction_mode == 1) {
+        om1 = P.materials[(size_t)s.mtl_index * 4 + 1];
+        eta_in = L.current_IOR;
+        eta_out = is_inside ? 1.0f : om1.w;
+    } else {
+        eta_in = L.current_IOR;
+        if (L.inside_of_count > 0) material = material_chooser(L, is_inside, (float)s.dielectric_priority, material);
+        if (material == L.in_mat[0]) {
+            // same medium on both sides: pass straight through (:1516-1528)
+            L.ignore_attenuation = 1;
+            if (L.refraction_bounces < P.push.max_refraction_bounces - 1) L.refraction_bounces++;
+            if (is_inside) remove_material_from_inside_of(L, s.mtl_index);
+            else add_material_to_inside_of(L, s.mtl_index, s.dielectric_priority);
+            return new_ray(offset_ray(s.point, -normal), ray_in.d);
+        }
+        om0 = P.materials[(size_t)material * 4];
+        om1 = P.materials[(size_t)material * 4 + 1];
+        eta_out = om1.w;
+        s.albedo = ld3(om0);
+    }
+    const float metallic = om1.x, opacity = om1.y;
+    if (opacity < 1.0f) {
+        // refract_ray, :1422-1479
+        if (is_inside) L.ignore_attenuation = 1;
+        float4 hm1 = P.materials[(size_t)s.mtl_index * 4 + 1];  // the hit object's own material
+        float eta = eta_in / eta_out;
+        float cos_theta = pmin(dot3(-ray_in.d, normal), 1.0f);
+        float sin_theta = psqrt(1.0f - cos_theta * cos_theta);
+        bool cannot_refract = eta * sin_theta > 1.0f;
+        bool do_reflect = cannot_refract;
+        if (!do_reflect) do_reflect = reflectance(eta, cos_theta) * hm1.z > noise(L);
+        if (do_reflect) return new_ray(offset_ray(s.point, normal), reflect3(ray_in.d, normal));
+        if (P.refraction_mode != 0) L.current_IOR = eta_out;
+        if (P.refraction_mode == 2) {
+            if (is_inside) remove_material_from_inside_of(L, s.mtl_index);
+            else {
+                float4 hm2 = P.materials[(size_t)s.mtl_index * 4 + 2];
+                add_material_to_inside_of(L, s.mtl_index, (int)fbits(hm2.x));
+            }
+        }
+        if (L.refraction_bounces < P.push.max_refraction_bounces - 1) L.refraction_bounces++;
+        return new_ray(offset_ray(s.point, -normal), refract3(ray_in.d, normal, eta));
+    }
+    if (metallic > 0.0f) {
+        // reflect_ray, :1340-1359
+        f3 new_origin = offset_ray(s.point, normal);
+        f3 reflected_dir = reflect3(ray_in.d, normal) * metallic;
+        f3 dir_offset = random_point_on_sphere(L) * (1.0f - metallic);
+        f3 ray_dir = reflected_dir + dir_offset;
+        if (dot3(ray_dir, normal) < 0.0f) ray_dir = reflect3(ray_dir, normal);
+        return new_ray(new_origin, ray_dir);
+    }
+    // scatter_ray, :1324-1338
+    f3 new_origin = offset_ray(s.point, normal);
+    f3 ray_dir = random_point_on_sphere(L) + normal;
+    if (near_zero3(ray_dir)) ray_dir = normal;
+    if (dot3(ray_dir, normal) < 0.0f) ray_dir = ray_dir * -1.0f;
+    return new_ray(new_origin, ray_dir);
+}
+
+// ---- camera ray and pixel store (main(), :1639-1705) -----------------------------------------------
+struct Primary {
+    Ray ray;
+    float seed;
+    int ux, uy;  // pixel in the image
+};
+PTK_DEV Primary primary_ray(const PtkPush& push, int gx, int gy) {  // :1645-1681
+    Primary pr;
+    f3 cam_pos = mk3(push.cam_pos[0], push.cam_pos[1], push.cam_pos[2]);
+    f3 right = mk3(push.cam_right[0], push.cam_right[1], push.cam_right[2]);
+    f3 up = mk3(push.cam_up[0], push.cam_up[1], push.cam_up[2]);
+    f3 forward = mk3(push.cam_forward[0], push.cam_forward[1], push.cam_forward[2]);
+    f3 viewport_u = right * push.viewport_width;
+    f3 viewport_v = (-up) * push.viewport_height;
+    f3 pixel_delta_u = div3(viewport_u, (float)push.width);
+    f3 pixel_delta_v = div3(viewport_v, (float)push.height);
+    f3 viewport_upper_left = (cam_pos - forward * push.focal_length) - div3(viewport_u + viewport_v, 2.0f);
+    f3 pixel00_loc = viewport_upper_left + (pixel_delta_u + pixel_delta_v) * 0.5f;
+    pr.ux = gx + push.image_offset_x;
+    pr.uy = gy + push.image_offset_y;
+    const float UVx = (float)pr.ux, UVy = (float)pr.uy;
+    f3 pixel_center = (pixel00_loc + pixel_delta_u * UVx) + pixel_delta_v * UVy;
+    pr.seed = hash3(UVx, UVy, push.time);
+    float jitter = pt_rand(push.time) - 1.0f;
+    f3 offset = div3(pixel_delta_u, 2.0f) * jitter + div3(pixel_delta_v, 2.0f) * jitter;
+    f3 ray_direction = normalize3((pixel_center - cam_pos) + offset);
+    pr.ray = new_ray(cam_pos, ray_direction);
+    return pr;
+}
+
+// gamma, accumulate, store (:1683-1704).  Returns whether the pixel lies inside the image.
+PTK_DEV bool store_pixel(const PtkParams& P, int ux, int uy, float4 new_color, bool override_color, float4 render_mode_color) {
+    const PtkPush& push = P.push;
+    const bool multisample = push.flags >= 0 && (push.flags & 2);
+    new_color.x = ppow(new_color.x, push.gamma);
+    new_color.y = ppow(new_color.y, push.gamma);
+    new_color.z = ppow(new_color.z, push.gamma);
+    const bool in_image = ux >= 0 && uy >= 0 && ux < P.img_w && uy < P.img_h;
+    const size_t pix = (size_t)uy * P.img_w + ux;
+    if (multisample) {
+        float4 prev = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (in_image) prev = P.image[pix];
+        float a = 1.0f / pmax(1.0f, push.frame);
+        float ia = 1.0f - a;
+        new_color = make_float4(prev.x * ia + new_color.x * a, prev.y * ia + new_color.y * a,
+                                prev.z * ia + new_color.z * a, prev.w * ia + new_color.w * a);
+    }
+    if (override_color) new_color = render_mode_color;
+    if (in_image) P.image[pix] = new_color;
+    return in_image;
+}
+
+}  // namespace

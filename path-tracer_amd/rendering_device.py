@@ -15,7 +15,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libptk.so")
+LIB_PATH = os.environ.get("PTK_LIBRARY") or os.path.join(_HERE, "csrc", "libptk.so")
 
 PTK_TRACE_PRIMARY_ID = 1
 PTK_TRACE_COUNTERS = 2
@@ -29,7 +29,10 @@ EXPORTS = [
     "ptk_buffer_read", "ptk_image_create", "ptk_image_read", "ptk_image_update", "ptk_texture_create",
     "ptk_dispatch", "ptk_sync", "ptk_free", "ptk_bvh_build", "ptk_bvh_sizes", "ptk_bvh_read",
     "ptk_trace_enable", "ptk_trace_read", "ptk_last_dispatch_ms", "ptk_dispatch_history_ms", "ptk_image_copy_device",
+    "ptk_set_renderer", "ptk_dispatch_traverse_ms",
 ]
+
+PTK_RENDERER_AUTO, PTK_RENDERER_SINGLE_KERNEL, PTK_RENDERER_WAVEFRONT = 0, 1, 2
 
 _lib = None
 
@@ -91,6 +94,10 @@ def load_library() -> C.CDLL:
     lib.ptk_dispatch_history_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     lib.ptk_image_copy_device.restype = C.c_int
     lib.ptk_image_copy_device.argtypes = [vp, u64, vp, C.c_size_t, C.c_int]
+    lib.ptk_set_renderer.restype = C.c_int
+    lib.ptk_set_renderer.argtypes = [vp, C.c_int]
+    lib.ptk_dispatch_traverse_ms.restype = C.c_int
+    lib.ptk_dispatch_traverse_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     _lib = lib
     return lib
 
@@ -239,6 +246,17 @@ class PtkRenderingDevice:
         arr = (C.c_float * n)()
         self._check(self.lib.ptk_dispatch_history_ms(self.ctx, arr, n), "ptk_dispatch_history_ms")
         return [float(x) for x in arr]
+
+    def set_renderer(self, renderer: int):
+        """PTK_RENDERER_AUTO / _SINGLE_KERNEL / _WAVEFRONT: the schedule used for the next dispatches."""
+        self._check(self.lib.ptk_set_renderer(self.ctx, int(renderer)), "ptk_set_renderer")
+
+    def dispatch_traverse_ms(self, back: int = 0):
+        """Durations of the traversal-kernel launches of the dispatch `back` calls ago ([] = one-kernel renderer)."""
+        arr = (C.c_float * 64)()
+        n = C.c_int(0)
+        self._check(self.lib.ptk_dispatch_traverse_ms(self.ctx, back, arr, 64, C.byref(n)), "ptk_dispatch_traverse_ms")
+        return [float(arr[k]) for k in range(n.value)]
 
     def image_copy_device(self, image: int, device_ptr: int, nbytes: int, to_image: bool):
         self._check(self.lib.ptk_image_copy_device(self.ctx, image, device_ptr, nbytes, int(to_image)), "ptk_image_copy_device")

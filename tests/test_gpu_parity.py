@@ -20,9 +20,16 @@ def rd(pta):
     dev.close()
 
 
-def _compare(name, gpu_img, cpu_img, gpu_ids, cpu_ids, gpu_cnt, cpu_cnt):
-    assert np.array_equal(gpu_ids, cpu_ids), f"{name}: {np.count_nonzero(gpu_ids != cpu_ids)} primary hit ids differ"
-    assert np.array_equal(gpu_cnt, cpu_cnt), f"{name}: traversal counters differ in {np.count_nonzero((gpu_cnt != cpu_cnt).any(-1))} pixels"
+@pytest.fixture(scope="module")
+def rd_wf(pta):
+    """A second context pinned to the wavefront renderer (untraced dispatches only)."""
+    dev = pta.PtkRenderingDevice(0)
+    dev.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
+    yield dev
+    dev.close()
+
+
+def _compare_image(name, gpu_img, cpu_img):
     both_nan = np.isnan(gpu_img) & np.isnan(cpu_img)
     diff = np.where(both_nan, 0.0, np.abs(gpu_img.astype(np.float64) - cpu_img.astype(np.float64)))
     assert not np.isnan(diff).any(), f"{name}: NaN on one side only"
@@ -32,9 +39,19 @@ def _compare(name, gpu_img, cpu_img, gpu_ids, cpu_ids, gpu_cnt, cpu_cnt):
     assert nbits == 0, f"{name}: {nbits} words differ bitwise (within tolerance, but the paths are meant to be identical)"
 
 
-def _run_case(pta, rd, golden_dir, name, w, h, depth, bounces, emission=False, dispatches=3, refraction_mode=2,
+def _compare(name, gpu_img, cpu_img, gpu_ids, cpu_ids, gpu_cnt, cpu_cnt):
+    assert np.array_equal(gpu_ids, cpu_ids), f"{name}: {np.count_nonzero(gpu_ids != cpu_ids)} primary hit ids differ"
+    assert np.array_equal(gpu_cnt, cpu_cnt), f"{name}: traversal counters differ in {np.count_nonzero((gpu_cnt != cpu_cnt).any(-1))} pixels"
+    _compare_image(name, gpu_img, cpu_img)
+
+
+def _run_case(pta, rd, rd_wf, golden_dir, name, w, h, depth, bounces, emission=False, dispatches=3, refraction_mode=2,
               early_t=False, scene=None, bvh_type=None, **win_kw):
+    """Renders `dispatches` progressive samples three ways: CPU oracle, the one-kernel renderer (traced:
+    primary ids + counters + image) and, where it applies and rd_wf is given, the wavefront renderer
+    (image).  Everything must match the oracle."""
     wd = pta.work_dispatcher
+    wf_applies = rd_wf is not None and not early_t and win_kw.get("render_mode", 0) not in (1, 2) and win_kw.get("use_bvh", True)
     if scene is None:
         scene = pta.scenes.load_fixture_scene(name, golden_dir)
     packed = wd.pack_scene(scene, ob.OracleBvhBuilder(), 8, bvh_type)
@@ -42,6 +59,11 @@ def _run_case(pta, rd, golden_dir, name, w, h, depth, bounces, emission=False, d
     disp.create_buffers(w, h, packed=packed)
     disp.load_shader(refraction_mode=refraction_mode, use_emission=emission, early_t_break=early_t)
     rd.trace_enable(3)
+    disp_wf = None
+    if wf_applies:
+        disp_wf = wd.PTWorkDispatcher(rd_wf)
+        disp_wf.create_buffers(w, h, packed=packed)
+        disp_wf.load_shader(refraction_mode=refraction_mode, use_emission=emission, early_t_break=False)
     win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=depth, max_refraction_bounces=bounces, **win_kw)
     cpu_img = np.zeros((h, w, 4), np.float32)
     try:
@@ -54,86 +76,92 @@ def _run_case(pta, rd, golden_dir, name, w, h, depth, bounces, emission=False, d
             gpu_img = rd.texture_get_data(disp.image_buffer)
             _compare(f"{name}[{k}]", gpu_img, cpu_img, rd.trace_read_primary(disp.image_buffer), out["primary_id"],
                      rd.trace_read_counters(disp.image_buffer), out["pixel_stats"])
+            if disp_wf is not None:
+                disp_wf.create_compute_list(win, scene.camera, t, sync=True)
+                assert len(rd_wf.dispatch_traverse_ms(0)) > 0, "the wavefront renderer did not run"
+                _compare_image(f"{name}[{k}] wavefront", rd_wf.texture_get_data(disp_wf.image_buffer), cpu_img)
     finally:
         rd.trace_enable(0)
         disp.free_rids()
+        if disp_wf is not None:
+            disp_wf.free_rids()
 
 
-def test_c1_sphere_scene1(pta, rd, golden_dir):
+def test_c1_sphere_scene1(pta, rd, rd_wf, golden_dir):
     """BASELINE config 1: sphere_scene1, 640x360, 1 spp, depth 4."""
-    _run_case(pta, rd, golden_dir, "sphere_scene1", 640, 360, 4, 4, dispatches=2)
+    _run_case(pta, rd, rd_wf, golden_dir, "sphere_scene1", 640, 360, 4, 4, dispatches=2)
 
 
-def test_c2_random_spheres(pta, rd, golden_dir):
+def test_c2_random_spheres(pta, rd, rd_wf, golden_dir):
     """BASELINE config 2 scene (487 spheres, diffuse/metal/glass, procedural textures), depth 8, reduced size."""
-    _run_case(pta, rd, golden_dir, "benchmark_random_scene", 640, 360, 8, 4, dispatches=3)
+    _run_case(pta, rd, rd_wf, golden_dir, "benchmark_random_scene", 640, 360, 8, 4, dispatches=3)
 
 
-def test_c3_cornell_emission(pta, rd, golden_dir):
+def test_c3_cornell_emission(pta, rd, rd_wf, golden_dir):
     """BASELINE config 3a: fake_cornell_box with USE_EMISSION 1."""
-    _run_case(pta, rd, golden_dir, "fake_cornell_box", 640, 360, 8, 8, emission=True, dispatches=3)
+    _run_case(pta, rd, rd_wf, golden_dir, "fake_cornell_box", 640, 360, 8, 8, emission=True, dispatches=3)
 
 
-def test_c3_nested_dielectrics(pta, rd, golden_dir):
+def test_c3_nested_dielectrics(pta, rd, rd_wf, golden_dir):
     """BASELINE config 3b: sphere_scene3 (priorities, air cut-outs)."""
-    _run_case(pta, rd, golden_dir, "sphere_scene3", 640, 360, 8, 8, dispatches=3)
+    _run_case(pta, rd, rd_wf, golden_dir, "sphere_scene3", 640, 360, 8, 8, dispatches=3)
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-def test_refraction_tracking_modes(pta, rd, golden_dir, mode):
+def test_refraction_tracking_modes(pta, rd, rd_wf, golden_dir, mode):
     """use_refraction_tracking 0 and 1 (ray_tracer.comp:84)."""
-    _run_case(pta, rd, golden_dir, "sphere_scene3", 320, 184, 6, 4, dispatches=2, refraction_mode=mode)
+    _run_case(pta, rd, rd_wf, golden_dir, "sphere_scene3", 320, 184, 6, 4, dispatches=2, refraction_mode=mode)
 
 
-def test_c4_dragon_instanced_mesh(pta, rd, golden_dir):
+def test_c4_dragon_instanced_mesh(pta, rd, rd_wf, golden_dir):
     """BASELINE config 4: dragon (8224 triangles) as one instanced PTMesh, XYZ_SORTED order 8, depth 4."""
-    _run_case(pta, rd, golden_dir, "dragon_test", 640, 360, 4, 4, dispatches=2)
+    _run_case(pta, rd, rd_wf, golden_dir, "dragon_test", 640, 360, 4, 4, dispatches=2)
 
 
-def test_mixed_scene_with_meshes(pta, rd, golden_dir):
+def test_mixed_scene_with_meshes(pta, rd, rd_wf, golden_dir):
     """test_scene_bvh_b: two PTMeshes (spheres and triangles inside meshes) plus scene-level objects."""
     scene = pta.scenes.load_fixture_scene("test_scene_bvh_b", golden_dir)
     scene.camera = pta.scene.PTCamera(transform=pta.godot_math.Transform3D.looking_at((4.0, 3.0, 6.0), (0.0, 0.0, 0.0)), fov=60.0)
-    _run_case(pta, rd, golden_dir, "test_scene_bvh_b", 320, 184, 5, 4, dispatches=2, scene=scene)
+    _run_case(pta, rd, rd_wf, golden_dir, "test_scene_bvh_b", 320, 184, 5, 4, dispatches=2, scene=scene)
 
 
-def test_early_t_break_variant(pta, rd, golden_dir):
+def test_early_t_break_variant(pta, rd, rd_wf, golden_dir):
     """use_early_t_break 1 (ray_tracer.comp:96,1128-1132,1280-1284)."""
-    _run_case(pta, rd, golden_dir, "benchmark_random_scene", 320, 184, 6, 4, dispatches=2, early_t=True)
-    _run_case(pta, rd, golden_dir, "dragon_test", 320, 184, 3, 4, dispatches=1, early_t=True)
+    _run_case(pta, rd, rd_wf, golden_dir, "benchmark_random_scene", 320, 184, 6, 4, dispatches=2, early_t=True)
+    _run_case(pta, rd, rd_wf, golden_dir, "dragon_test", 320, 184, 3, 4, dispatches=1, early_t=True)
 
 
-def test_render_modes(pta, rd, golden_dir):
+def test_render_modes(pta, rd, rd_wf, golden_dir):
     """BVH heat view and normal view (ray_tracer.comp:1567-1570,1624-1632)."""
-    _run_case(pta, rd, golden_dir, "benchmark_random_scene", 320, 184, 8, 4, dispatches=1, render_mode=1,
+    _run_case(pta, rd, rd_wf, golden_dir, "benchmark_random_scene", 320, 184, 8, 4, dispatches=1, render_mode=1,
               display_node_count=True, display_object_count=True)
-    _run_case(pta, rd, golden_dir, "sphere_scene3", 320, 184, 8, 4, dispatches=1, render_mode=2)
+    _run_case(pta, rd, rd_wf, golden_dir, "sphere_scene3", 320, 184, 8, 4, dispatches=1, render_mode=2)
 
 
-def test_brute_force_mode(pta, rd, golden_dir):
+def test_brute_force_mode(pta, rd, rd_wf, golden_dir):
     """USE_BVH flag off: linear scans (ray_tracer.comp:1093-1101)."""
-    _run_case(pta, rd, golden_dir, "sphere_scene1", 160, 96, 4, 4, dispatches=1, use_bvh=False)
-    _run_case(pta, rd, golden_dir, "fake_cornell_box", 160, 96, 4, 4, dispatches=1, use_bvh=False)
+    _run_case(pta, rd, rd_wf, golden_dir, "sphere_scene1", 160, 96, 4, 4, dispatches=1, use_bvh=False)
+    _run_case(pta, rd, rd_wf, golden_dir, "fake_cornell_box", 160, 96, 4, 4, dispatches=1, use_bvh=False)
 
 
-def test_no_multisample_overwrites(pta, rd, golden_dir):
-    _run_case(pta, rd, golden_dir, "sphere_scene1", 160, 96, 4, 4, dispatches=2, enable_multisampling=False)
+def test_no_multisample_overwrites(pta, rd, rd_wf, golden_dir):
+    _run_case(pta, rd, rd_wf, golden_dir, "sphere_scene1", 160, 96, 4, 4, dispatches=2, enable_multisampling=False)
 
 
-def test_atrium_standin_small(pta, rd, golden_dir):
+def test_atrium_standin_small(pta, rd, rd_wf, golden_dir):
     """The Sponza stand-in generator at a size the oracle renders in seconds (16 384 triangles)."""
     scene = pta.scenes.atrium_scene(16384, seed=7)
-    _run_case(pta, rd, golden_dir, "atrium16k", 320, 184, 8, 4, dispatches=2, scene=scene)
+    _run_case(pta, rd, rd_wf, golden_dir, "atrium16k", 320, 184, 8, 4, dispatches=2, scene=scene)
 
 
-def test_random_spheres_10k(pta, rd, golden_dir):
+def test_random_spheres_10k(pta, rd, rd_wf, golden_dir):
     """Scaled variant of the random scene: ~10 000 spheres."""
     scene = pta.scenes.random_spheres_scene(grid=50, seed=3)
-    _run_case(pta, rd, golden_dir, "spheres10k", 320, 184, 8, 4, dispatches=2, scene=scene)
+    _run_case(pta, rd, rd_wf, golden_dir, "spheres10k", 320, 184, 8, 4, dispatches=2, scene=scene)
 
 
 # ---- size-independent properties at full BASELINE sizes ------------------------------------------
-def test_full_size_tiles_equal_whole(pta, rd, golden_dir):
+def test_full_size_tiles_equal_whole(pta, rd, rd_wf, golden_dir):
     """1920x1080: rendering the frame as four tiles (image_offset push constants) gives the same image
     as one dispatch, bit for bit (the seed depends only on absolute pixel coordinates and time)."""
     wd = pta.work_dispatcher

@@ -1,0 +1,27 @@
+"""Kernel time of the bench workload with whatever libptk PTK_LIBRARY names (development aid)."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pta = importlib.import_module("path-tracer_amd")
+wd = pta.work_dispatcher
+w, h = 1920, 1080
+which = sys.argv[1] if len(sys.argv) > 1 else "atrium"
+scene = pta.scenes.atrium_scene(262144, seed=7) if which == "atrium" else pta.scenes.random_spheres_scene(100, 3)
+rd = pta.PtkRenderingDevice(0)
+rd.set_renderer(int(os.environ.get("PTK_RENDERER", "0")))
+disp = wd.PTWorkDispatcher(rd)
+disp.set_scene(scene)
+disp.create_buffers(w, h, order=8)
+disp.load_shader(refraction_mode=2, use_emission=False, early_t_break=False)
+win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=8, max_refraction_bounces=4)
+for k in range(8):
+    win.frame = k
+    disp.create_compute_list(win, scene.camera, wd.sample_time(k))
+rd.sync()
+ms = rd.dispatch_history_ms(6)
+tr = rd.dispatch_traverse_ms(0)
+print("traverse launches ms", ["%.3f" % x for x in tr], "sum %.3f" % sum(tr))
+img = rd.texture_get_data(disp.image_buffer)
+import zlib
+print(os.environ.get("PTK_LIBRARY", "default"), which, "kernel ms median %.3f" % float(np.median(ms)), "crc %08x" % zlib.crc32(bytes(img)))
