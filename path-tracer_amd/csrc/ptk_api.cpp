@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <string>
@@ -68,6 +69,7 @@ struct ptk_ctx {
     int renderer = PTK_RENDERER_AUTO;
     bool wf_ok = false;            // scene has no mesh socket below another mesh socket
     float4* d_rt_nodes = nullptr;  // nodes with traversal entries in the w words
+    float4* d_leaf_records = nullptr;  // per object-id slot: the primitive by value (48 bytes)
     void* d_wf = nullptr;          // queues + path state, one allocation
     size_t wf_slots = 0;
     int* d_wf_spill = nullptr;
@@ -164,6 +166,7 @@ void ptk_destroy(ptk_ctx* ctx) {
     if (ctx->d_trace_primary) (void)hipFree(ctx->d_trace_primary);
     if (ctx->d_trace_counters) (void)hipFree(ctx->d_trace_counters);
     if (ctx->d_rt_nodes) (void)hipFree(ctx->d_rt_nodes);
+    if (ctx->d_leaf_records) (void)hipFree(ctx->d_leaf_records);
     if (ctx->d_wf) (void)hipFree(ctx->d_wf);
     if (ctx->d_wf_spill) (void)hipFree(ctx->d_wf_spill);
     for (int i = 0; i < ptk_ctx::kTimingRing; i++) {
@@ -472,6 +475,27 @@ static int validate_scene(ptk_ctx* ctx) {
     if (ctx->stack_need > 1024)
         return fail(ctx, PTK_E_UNSUPPORTED, "BVH can need %d stack entries; the reference's traversal stack holds 1024", ctx->stack_need);
 
+    // leaf records: what a leaf tests for object-id slot i, by value, so the traversal kernel reads a
+    // leaf's primitives from consecutive addresses without going through the id table first
+    std::vector<float> leaf_records((size_t)std::max(n_ids, 1) * 12, 0.0f);
+    for (int i = 0; i < n_ids; i++) {
+        const int oid = idp[i];
+        const int type = sext(oid, 24, 8), oi = sext(oid, 0, 24);
+        float* r = leaf_records.data() + (size_t)i * 12;
+        if (type == 3 && oi >= 0 && oi < n_tri) {
+            const uint8_t* t = tri->shadow.data() + (size_t)oi * 80;
+            memcpy(r + 0, t + 0, 12); memcpy(r + 4, t + 16, 12); memcpy(r + 8, t + 32, 12);
+            memcpy(r + 3, &oid, 4);
+        } else if (type == 1 && oi >= 0 && oi < n_sph) {
+            const uint8_t* sp = sph->shadow.data() + (size_t)oi * 32;
+            memcpy(r + 0, sp, 12); memcpy(r + 4, sp + 12, 4);
+            memcpy(r + 3, &oid, 4);
+        }
+    }
+    if (ctx->d_leaf_records) { (void)hipFree(ctx->d_leaf_records); ctx->d_leaf_records = nullptr; }
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_leaf_records, leaf_records.size() * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_leaf_records, leaf_records.data(), leaf_records.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+
     // planes with a non-zero normal, in index order
     std::vector<int> live;
     for (int i = 0; i < n_pln; i++) {
@@ -651,7 +675,7 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     if (n_slots > ctx->wf_slots) {
         if (ctx->d_wf) { (void)hipFree(ctx->d_wf); ctx->d_wf = nullptr; }
         ctx->wf_slots = 0;
-        const size_t per_slot = 2 * 32 + 16 + 8 + 16 + 4 + 4 + 8 + 40;
+        const size_t per_slot = 2 * 32 + 2 * 32 + 16 + 8 + 40;  // rays x2, state x2, hits, hit uv, inside arrays
         HIP_TRY(ctx, hipMalloc(&ctx->d_wf, n_slots * per_slot + 1024));
         ctx->wf_slots = n_slots;
     }
@@ -663,22 +687,22 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         base += 1024;
         P.wf.rays[0] = (float4*)base; base += cap * 32;
         P.wf.rays[1] = (float4*)base; base += cap * 32;
+        P.wf.state[0] = (float4*)base; base += cap * 32;
+        P.wf.state[1] = (float4*)base; base += cap * 32;
         P.wf.hits = (int4*)base; base += cap * 16;
-        P.wf.color = (float4*)base; base += cap * 16;
         P.wf.hit_uv = (float2*)base; base += cap * 8;
-        P.wf.misc = (int2*)base; base += cap * 8;
-        P.wf.seed = (float*)base; base += cap * 4;
-        P.wf.ior = (float*)base; base += cap * 4;
         P.wf.inside = (int*)base;
         P.wf.n_slots = (uint32_t)n_slots;
         P.wf.tiles_x = groups_x;
         P.wf.rt_nodes = ctx->d_rt_nodes;
+        P.wf.leaf_records = ctx->d_leaf_records;
     }
     // persistent traversal waves: as many as fit on the device at once
     const size_t wf_lds = (size_t)(P.lds_cap + 1) * 64 * 4;  // one spare row for rejected children
     int waves_per_cu = 0;
     HIP_TRY(ctx, ptk_wavefront_occupancy(wf_lds, &waves_per_cu));
     if (waves_per_cu <= 0) return fail(ctx, PTK_E_HIP, "the traversal kernel does not fit on a compute unit");
+    if (const char* cap = getenv("PTK_WF_WAVES_PER_CU")) waves_per_cu = std::max(1, std::min(waves_per_cu, atoi(cap)));  // tuning aid
     const int n_waves = (int)std::min<size_t>((size_t)waves_per_cu * std::max(ctx->n_cus, 1), (n_slots + 63) / 64);
     P.spill = nullptr;
     P.spill_t = nullptr;
@@ -704,6 +728,16 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     ctx->dispatch_count++;
     return PTK_OK;
 }
+
+#ifdef PTK_ROUND_STATS
+// development build only: round counters of the traversal kernel (zeroed with the queue heads every dispatch)
+int ptk_debug_wf_stats(ptk_ctx* ctx, unsigned long long* out16) {
+    if (!ctx || !ctx->d_wf) return PTK_E_STATE;
+    HIP_TRY(ctx, hipMemcpyAsync(out16, (uint8_t*)ctx->d_wf + 512, 128, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTK_OK;
+}
+#endif
 
 int ptk_set_renderer(ptk_ctx* ctx, int renderer) {
     if (!ctx) return PTK_E_INVALID;

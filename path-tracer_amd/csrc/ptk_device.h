@@ -36,7 +36,8 @@ struct PtkTexDesc {
 };
 
 // Wavefront renderer state: ray queues, hit records and per-pixel path state in HBM.
-// A queue entry is two float4: {origin.xyz, bits(pixel slot)}, {direction.xyz, 0}; the hit record of
+// A queue entry is two float4: {origin.xyz, bits(pixel slot)}, {direction.xyz, 0}, plus the path state
+// in a parallel array that only the shading kernel touches; the hit record of
 // entry i is hits[i] = {hit, object_id, transform_index, bits(t)} and hit_uv[i].
 #define PTK_WF_MAX_ITER 32
 struct PtkWavefront {
@@ -45,14 +46,14 @@ struct PtkWavefront {
     float2* hit_uv;
     uint32_t* counts;  // counts[i] = rays queued for bounce i          (PTK_WF_MAX_ITER + 1 words)
     uint32_t* heads;   // heads[i]  = rays of bounce i handed to waves  (PTK_WF_MAX_ITER + 1 words)
-    float4* color;     // path throughput, per pixel slot
-    float* seed;
-    float* ior;
-    int2* misc;        // {inside_of_count, refraction_bounces | inside-arrays-stored << 30}
+    float4* state[2];  // path state travelling with the queue entry, two float4 per entry:
+                       // {throughput rgba}, {seed, current_IOR, bits(inside_of_count),
+                       //  bits(refraction_bounces | inside-arrays-stored << 30)}
     int* inside;       // [10][n_slots]: in_mat[0..4], in_pri[0..4]
     uint32_t n_slots;  // groups_x * groups_y * 64
     int tiles_x;
     const float4* rt_nodes;  // node buffer whose w words hold the traversal entry of each node
+    const float4* leaf_records;  // 3 float4 per object-id slot: the primitive a leaf tests, by value
 };
 
 struct PtkParams {

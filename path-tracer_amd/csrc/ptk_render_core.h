@@ -132,13 +132,11 @@ PTK_DEV float hit_aabb(float4 bmin, float4 bmax, f3 o, f3 inv, int neg_mask, flo
     return start;
 }
 
-template <bool TRACE>
-PTK_DEV void hit_sphere_gems(const PtkParams& P, Ray& ray, Hit& h, int object_id, int cur_xf, int* cnt) {  // :803-841
-    float4 s = P.spheres[(size_t)bfe_i(object_id, 0, 24) * 2];
-    if (TRACE) cnt[PTK_CNT_SPHERE_TESTS]++;
-    f3 oc = ray.o - ld3(s);
+// Ray-sphere test on a sphere given by value (:803-841).
+PTK_DEV void hit_sphere_rec(Ray& ray, Hit& h, int object_id, int cur_xf, f3 center, float radius) {
+    f3 oc = ray.o - center;
     float half_b = dot3(-oc, ray.d);
-    float r_sqrd = s.w * s.w;
+    float r_sqrd = radius * radius;
     f3 temp = oc + ray.d * half_b;
     float discriminant = r_sqrd - dot3(temp, temp);
     if (discriminant < 0.0f) return;
@@ -152,6 +150,12 @@ PTK_DEV void hit_sphere_gems(const PtkParams& P, Ray& ray, Hit& h, int object_id
     }
     h.hit = 1; h.object_id = object_id; h.transform_index = cur_xf;
     ray.end = root;
+}
+template <bool TRACE>
+PTK_DEV void hit_sphere_gems(const PtkParams& P, Ray& ray, Hit& h, int object_id, int cur_xf, int* cnt) {
+    float4 s = P.spheres[(size_t)bfe_i(object_id, 0, 24) * 2];
+    if (TRACE) cnt[PTK_CNT_SPHERE_TESTS]++;
+    hit_sphere_rec(ray, h, object_id, cur_xf, ld3(s), s.w);
 }
 
 PTK_DEV void hit_sphere_plain(const PtkParams& P, Ray& ray, Hit& h, int object_id, int cur_xf) {  // :691-727
@@ -172,11 +176,8 @@ PTK_DEV void hit_sphere_plain(const PtkParams& P, Ray& ray, Hit& h, int object_i
     ray.end = root;
 }
 
-template <bool TRACE>
-PTK_DEV void hit_triangle_mt(const PtkParams& P, Ray& ray, Hit& h, int object_id, int cur_xf, int* cnt) {  // :926-969
-    const float4* t = P.triangles + (size_t)bfe_i(object_id, 0, 24) * 5;
-    if (TRACE) cnt[PTK_CNT_TRI_TESTS]++;
-    f3 A = ld3(t[0]), B = ld3(t[1]), C = ld3(t[2]);
+// Moeller-Trumbore on a triangle given by value (:926-969).
+PTK_DEV void hit_triangle_rec(Ray& ray, Hit& h, int object_id, int cur_xf, f3 A, f3 B, f3 C) {
     f3 E1 = B - A, E2 = C - A;
     f3 N = cross3(E1, E2);
     float det = -dot3(ray.d, N);
@@ -193,6 +194,12 @@ PTK_DEV void hit_triangle_mt(const PtkParams& P, Ray& ray, Hit& h, int object_id
         h.u = u; h.v = v;
         ray.end = tt;
     }
+}
+template <bool TRACE>
+PTK_DEV void hit_triangle_mt(const PtkParams& P, Ray& ray, Hit& h, int object_id, int cur_xf, int* cnt) {
+    const float4* t = P.triangles + (size_t)bfe_i(object_id, 0, 24) * 5;
+    if (TRACE) cnt[PTK_CNT_TRI_TESTS]++;
+    hit_triangle_rec(ray, h, object_id, cur_xf, ld3(t[0]), ld3(t[1]), ld3(t[2]));
 }
 
 PTK_DEV void hit_plane(const PtkParams& P, Ray& ray, Hit& h, int index, int cur_xf) {  // :851-875

@@ -23,6 +23,7 @@ namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+constexpr int SHADE_BLOCK = 512;    // threads per shading block (one queue reservation per block)
 constexpr uint32_t WF_CHUNK = 64;  // rays a wave claims from the queue per atomic
 #ifndef PTK_WF_REFILL
 #define PTK_WF_REFILL 12           // lanes without work that make the wave run a refill round
@@ -49,10 +50,8 @@ __global__ __launch_bounds__(64) void ptk_wf_generate(const PtkParams P) {
     const Primary pr = primary_ray(P.push, gx, gy);
     W.rays[0][(size_t)slot * 2] = make_float4(pr.ray.o.x, pr.ray.o.y, pr.ray.o.z, bitsf(slot));
     W.rays[0][(size_t)slot * 2 + 1] = make_float4(pr.ray.d.x, pr.ray.d.y, pr.ray.d.z, 0.0f);
-    W.color[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-    W.seed[slot] = pr.seed;
-    W.ior[slot] = 1.0f;
-    W.misc[slot] = make_int2(0, 0);
+    W.state[0][(size_t)slot * 2] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    W.state[0][(size_t)slot * 2 + 1] = make_float4(pr.seed, 1.0f, bitsf(0u), bitsf(0u));
 }
 
 // Closest hit of every ray of bounce `iter`.  Per lane this is check_ray_hit_bvh2 of
@@ -95,7 +94,13 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
         const unsigned long long mi = __ballot(is_inner), ml = __ballot(is_leaf);
         const int n_idle = 64 - __popcll(mi | ml);
 
+#ifdef PTK_ROUND_STATS
+#define PTK_STAT(k, v) do { if (lane == 0) atomicAdd((unsigned long long*)(W.counts + 128) + (k), (unsigned long long)(v)); } while (0)
+#else
+#define PTK_STAT(k, v) do { } while (0)
+#endif
         if ((mi | ml) == 0ull || (!exhausted && n_idle >= PTK_WF_REFILL)) {
+            PTK_STAT(0, 1); PTK_STAT(1, n_idle);
             // ---- refill round: retire finished rays, claim new ones ----
             if (have && !has) {
                 W.hits[ray_idx] = make_int4(h.hit, h.object_id, h.transform_index, (int)fbits(ray.end));
@@ -146,6 +151,7 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
         bool refill = false;
         if (__popcll(mi) >= __popcll(ml)) {
             // ---- inner round ----
+            PTK_STAT(2, 1); PTK_STAT(3, __popcll(mi)); PTK_STAT(4, __popcll(__ballot(is_inner && (cur & 0xFF000000u) == SOCKET_MARK)));
             if (is_inner) {
                 if ((cur & 0xFF000000u) == SOCKET_MARK) {
                     // world level: enter the mesh (:1286-1313); its root is the next node
@@ -183,8 +189,11 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
                     __builtin_amdgcn_sched_barrier(0);
                     const v2f oxy = {ray.o.x, ray.o.y}, ixy = {inv.x, inv.y};
                     const bool nx = (neg & 1) != 0, ny = (neg & 2) != 0, nz = (neg & 4) != 0;
-                    float ts[PTK_MAX_WIDTH];
-                    int rank[PTK_MAX_WIDTH];
+                    // a NaN in the ray's own range (singular mesh transform) fails in_range for every box
+                    const bool range_ok = ray.start == ray.start && ray.end == ray.end;
+                    // key = bits of the entry distance t (t >= +0, so unsigned integer order is float
+                    // order); rejected children get the bits of +inf, which no accepted t reaches
+                    uint32_t key[PTK_MAX_WIDTH];
                     int added = 0;
 #pragma unroll
                     for (int l = 0; l < PTK_MAX_WIDTH; l++) {
@@ -205,63 +214,85 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
                         end = __builtin_fminf(end, ny ? sb.y : t1.y);
                         start = __builtin_fmaxf(start, nz ? scz : t0z);
                         end = __builtin_fminf(end, nz ? sbz : t1z);
-                        const bool acc = (l < node_size) && (end > start);
-                        ts[l] = acc ? start : PT_INF;
+                        const bool acc = (l < node_size) && (end > start) && range_ok;
+                        key[l] = acc ? (fbits(start) & 0x7FFFFFFFu) : 0x7F800000u;
                         added += acc ? 1 : 0;
-                        rank[l] = 0;
                     }
                     // rank = number of children the shader's selection loop (:1157-1178) would take
-                    // earlier: smaller t, or equal t in a lower slot.  Each unordered pair is compared once.
+                    // earlier: smaller t, or equal t in a lower slot.  For j < l, u = 1 iff child l is
+                    // strictly nearer than child j (sign bit of key[l] - key[j]; both keys < 2^31):
+                    // rank[l] = l - sum_{j<l} u(j,l) + sum_{m>l} u(l,m).
+                    int up[PTK_MAX_WIDTH], dn[PTK_MAX_WIDTH];
+#pragma unroll
+                    for (int l = 0; l < PTK_MAX_WIDTH; l++) { up[l] = 0; dn[l] = 0; }
 #pragma unroll
                     for (int l = 1; l < PTK_MAX_WIDTH; l++) {
 #pragma unroll
                         for (int j = 0; j < l; j++) {
-                            const int c = (ts[j] <= ts[l]) ? 1 : 0;
-                            rank[l] += c;
-                            rank[j] += 1 - c;
+                            const int u = (int)((key[l] - key[j]) >> 31);
+                            up[j] += u;
+                            dn[l] += u;
                         }
                     }
-                    // rank r goes to stack slot sp + added - 1 - r; rank 0 (nearest) becomes `cur`
-                    // (it also lands in the free slot above the new top).  Rejected children have
-                    // rank >= added; they are sent to a spare row.
+                    // rank r goes to stack slot sp + added - 1 - r, so the nearest child lands in the free
+                    // slot above the new top and is read back as `cur`; rejected children (rank >= added)
+                    // are sent to a spare row.
                     cur = ENTRY_NONE;
                     const int top = sp + added - 1;
                     if (sp + PTK_MAX_WIDTH <= S.lds_cap) {
 #pragma unroll
                         for (int l = 0; l < PTK_MAX_WIDTH; l++) {
-                            const bool acc = ts[l] < PT_INF;
-                            const uint32_t e = fbits(bmin[l].w);
-                            lds_lane[(acc ? top - rank[l] : S.lds_cap) * 64] = (int)e;
-                            cur = (acc && rank[l] == 0) ? e : cur;
+                            const int rank = l - dn[l] + up[l];
+                            lds_lane[((key[l] != 0x7F800000u) ? top - rank : S.lds_cap) * 64] = (int)fbits(bmin[l].w);
                         }
+                        if (added > 0) cur = (uint32_t)lds_lane[top * 64];
                     } else {
 #pragma unroll
                         for (int l = 0; l < PTK_MAX_WIDTH; l++) {
-                            if (ts[l] < PT_INF) {
-                                if (rank[l] == 0) cur = fbits(bmin[l].w);
-                                else st_write(S, top - rank[l], (int)fbits(bmin[l].w));
+                            const int rank = l - dn[l] + up[l];
+                            if (key[l] != 0x7F800000u) {
+                                if (rank == 0) cur = fbits(bmin[l].w);
+                                else st_write(S, top - rank, (int)fbits(bmin[l].w));
                             }
                         }
                     }
                     sp += (added > 0) ? added - 1 : 0;
                     refill = added == 0;
+#ifdef PTK_ROUND_STATS
+                    {
+                        const int c0 = __popcll(__ballot(added == 0)), c1 = __popcll(__ballot(added == 1)), c2 = __popcll(__ballot(added == 2));
+                        const int c3 = __popcll(__ballot(added == 3)), c4 = __popcll(__ballot(added >= 4));
+                        const unsigned long long act = __ballot(true);
+                        if (lane == __ffsll((long long)act) - 1) {
+                            unsigned long long* st = (unsigned long long*)(W.counts + 128);
+                            atomicAdd(st + 9, (unsigned long long)c0); atomicAdd(st + 10, (unsigned long long)c1); atomicAdd(st + 11, (unsigned long long)c2);
+                            atomicAdd(st + 12, (unsigned long long)c3); atomicAdd(st + 13, (unsigned long long)c4);
+                            atomicAdd(st + 14, (unsigned long long)((c3 + c4) > 0)); atomicAdd(st + 15, 1ull);
+                        }
+                    }
+#endif
                 }
             }
         } else {
             // ---- leaf round: the objects of the leaf, in order (:1137-1142) ----
+            PTK_STAT(5, 1); PTK_STAT(6, __popcll(ml));
             int node_size = 0, base = 0;
             if (is_leaf) {
                 node_size = iabs(bfe_i((int)cur, 24, 8));
                 base = iabs(bfe_i((int)cur, 0, 24)) - 1;
             }
+            // leaf records: {A.xyz | centre.xyz, object id}, {B.xyz | radius, -}, {C.xyz, -}, stored in
+            // object-id-slot order, so a leaf's objects are contiguous and need no id lookup first
+            const float4* __restrict__ rec = W.leaf_records + (size_t)base * 3;
             for (int k = 0;; k++) {
                 const bool go = k < node_size;
                 if (__ballot(go) == 0ull) break;
                 if (go) {
-                    const int object_id = P.object_ids[base + k];
+                    const float4 r0 = rec[k * 3], r1 = rec[k * 3 + 1], r2 = rec[k * 3 + 2];
+                    const int object_id = (int)fbits(r0.w);
                     const int type = bfe_i(object_id, 24, 8);
-                    if (type == IS_TRIANGLE) hit_triangle_mt<false>(P, ray, h, object_id, cur_xf, nullptr);
-                    else if (type == IS_SPHERE) hit_sphere_gems<false>(P, ray, h, object_id, cur_xf, nullptr);
+                    if (type == IS_TRIANGLE) hit_triangle_rec(ray, h, object_id, cur_xf, ld3(r0), ld3(r1), ld3(r2));
+                    else if (type == IS_SPHERE) hit_sphere_rec(ray, h, object_id, cur_xf, ld3(r0), r1.x);
                 }
             }
             refill = is_leaf;
@@ -285,83 +316,109 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
 
 // The bounce-loop body after the closest-hit search (:1583-1621) for every ray of bounce `iter`, and
 // the end of main() (:1683-1704) for the paths that stop here.
-__global__ __launch_bounds__(64) void ptk_wf_shade(const PtkParams P, int iter) {
+__global__ __launch_bounds__(SHADE_BLOCK) void ptk_wf_shade(const PtkParams P, int iter) {
+    __shared__ uint32_t s_wave_total[SHADE_BLOCK / 64];
+    __shared__ uint32_t s_base;
     const PtkWavefront& W = P.wf;
-    const uint32_t idx = blockIdx.x * 64u + threadIdx.x;
     const uint32_t count = W.counts[iter];
-    if (idx >= count) return;
-    const float4 qa = W.rays[iter & 1][(size_t)idx * 2], qb = W.rays[iter & 1][(size_t)idx * 2 + 1];
-    const uint32_t slot = fbits(qa.w);
-    const int4 hr = W.hits[idx];
-    const float2 uv = W.hit_uv[idx];
-    Ray nr;
-    nr.o = mk3(qa.x, qa.y, qa.z);
-    nr.start = 0.0f;
-    nr.d = mk3(qb.x, qb.y, qb.z);
-    nr.end = bitsf((uint32_t)hr.w);
-    Hit h;
-    h.hit = hr.x; h.object_id = hr.y; h.transform_index = hr.z; h.u = uv.x; h.v = uv.y;
-
-    Lane L;
-    L.seed = W.seed[slot];
-    L.current_IOR = W.ior[slot];
-    const int2 misc = W.misc[slot];
-    L.inside_of_count = misc.x;
-    L.refraction_bounces = misc.y & 0x3FFFFFFF;
-    const bool inside_stored = ((misc.y >> 30) & 1) != 0;
-    L.is_emissive = 0; L.ignore_attenuation = 0; L.node_hit_count = 0; L.object_hit_count = 0;
+    if (blockIdx.x * (uint32_t)SHADE_BLOCK >= count) return;  // the whole block is past the queue's end
+    const uint32_t idx = blockIdx.x * (uint32_t)SHADE_BLOCK + threadIdx.x;
     const bool track_inside = P.refraction_mode == 2;
-#pragma unroll
-    for (int i = 0; i < MAX_OVERLAP; i++) {
-        L.in_mat[i] = 0;
-        L.in_pri[i] = INT_NEG_LIMIT;
-        if (track_inside && inside_stored) {
-            L.in_mat[i] = W.inside[(size_t)i * W.n_slots + slot];
-            L.in_pri[i] = W.inside[(size_t)(MAX_OVERLAP + i) * W.n_slots + slot];
-        }
-    }
+    uint32_t slot = 0;
+    Ray nr;
+    nr.o = mk3(0, 0, 0); nr.d = mk3(0, 0, 1); nr.start = 0.0f; nr.end = 0.0f;
+    Lane L;
+    L.seed = 0.0f; L.current_IOR = 1.0f; L.inside_of_count = 0; L.refraction_bounces = 0;
+    float4 new_color = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    bool inside_stored = false;
+    bool going = false;
+    if (idx < count) {
+        const float4 qa = W.rays[iter & 1][(size_t)idx * 2], qb = W.rays[iter & 1][(size_t)idx * 2 + 1];
+        slot = fbits(qa.w);
+        const int4 hr = W.hits[idx];
+        const float2 uv = W.hit_uv[idx];
+        nr.o = mk3(qa.x, qa.y, qa.z);
+        nr.start = 0.0f;
+        nr.d = mk3(qb.x, qb.y, qb.z);
+        nr.end = bitsf((uint32_t)hr.w);
+        Hit h;
+        h.hit = hr.x; h.object_id = hr.y; h.transform_index = hr.z; h.u = uv.x; h.v = uv.y;
 
-    float4 new_color = W.color[slot];
-    bool done = false;
-    if (!h.hit) {
-        const float4 sky = P.use_emission ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(0.7f, 0.7f, 0.9f, 1.0f);
-        new_color = make_float4(new_color.x * sky.x, new_color.y * sky.y, new_color.z * sky.z, new_color.w * sky.w);
-        done = true;
-    } else {
-        Surf s = determine_rayhit<false>(P, L, nr, h, nullptr);
-        if (P.use_emission && L.is_emissive) {
-            new_color = make_float4(new_color.x * s.albedo.x, new_color.y * s.albedo.y, new_color.z * s.albedo.z, new_color.w * 1.0f);
+        const float4 st0 = W.state[iter & 1][(size_t)idx * 2], st1 = W.state[iter & 1][(size_t)idx * 2 + 1];
+        L.seed = st1.x;
+        L.current_IOR = st1.y;
+        L.inside_of_count = (int)fbits(st1.z);
+        const int misc = (int)fbits(st1.w);
+        L.refraction_bounces = misc & 0x3FFFFFFF;
+        inside_stored = ((misc >> 30) & 1) != 0;
+        L.is_emissive = 0; L.ignore_attenuation = 0; L.node_hit_count = 0; L.object_hit_count = 0;
+        const bool track_inside = P.refraction_mode == 2;
+    #pragma unroll
+        for (int i = 0; i < MAX_OVERLAP; i++) {
+            L.in_mat[i] = 0;
+            L.in_pri[i] = INT_NEG_LIMIT;
+            if (track_inside && inside_stored) {
+                L.in_mat[i] = W.inside[(size_t)i * W.n_slots + slot];
+                L.in_pri[i] = W.inside[(size_t)(MAX_OVERLAP + i) * W.n_slots + slot];
+            }
+        }
+
+        new_color = st0;
+        bool done = false;
+        if (!h.hit) {
+            const float4 sky = P.use_emission ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(0.7f, 0.7f, 0.9f, 1.0f);
+            new_color = make_float4(new_color.x * sky.x, new_color.y * sky.y, new_color.z * sky.z, new_color.w * sky.w);
             done = true;
         } else {
-            const float4 tex_col = get_texture(P, s);
-            nr = bounce_ray(P, L, nr, s);
-            if (!L.ignore_attenuation) {
-                new_color.x *= s.albedo.x * tex_col.x;
-                new_color.y *= s.albedo.y * tex_col.y;
-                new_color.z *= s.albedo.z * tex_col.z;
-                new_color.w *= 1.0f * tex_col.w;
+            Surf s = determine_rayhit<false>(P, L, nr, h, nullptr);
+            if (P.use_emission && L.is_emissive) {
+                new_color = make_float4(new_color.x * s.albedo.x, new_color.y * s.albedo.y, new_color.z * s.albedo.z, new_color.w * 1.0f);
+                done = true;
+            } else {
+                const float4 tex_col = get_texture(P, s);
+                nr = bounce_ray(P, L, nr, s);
+                if (!L.ignore_attenuation) {
+                    new_color.x *= s.albedo.x * tex_col.x;
+                    new_color.y *= s.albedo.y * tex_col.y;
+                    new_color.z *= s.albedo.z * tex_col.z;
+                    new_color.w *= 1.0f * tex_col.w;
+                }
+                done = !(iter + 1 < P.push.max_default_depth + L.refraction_bounces);
             }
-            done = !(iter + 1 < P.push.max_default_depth + L.refraction_bounces);
+        }
+
+        if (done) {
+            if (P.use_emission && !L.is_emissive) new_color = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            int gx, gy;
+            slot_to_pixel(P, slot, gx, gy);
+            store_pixel(P, gx + P.push.image_offset_x, gy + P.push.image_offset_y, new_color, false, new_color);
+        } else {
+            going = true;
         }
     }
 
-    if (done) {
-        if (P.use_emission && !L.is_emissive) new_color = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        int gx, gy;
-        slot_to_pixel(P, slot, gx, gy);
-        store_pixel(P, gx + P.push.image_offset_x, gy + P.push.image_offset_y, new_color, false, new_color);
-        return;
+    // Paths that go on queue their next ray together with the path state.  The block reserves its
+    // range of the next queue with one atomic (one per wave would serialise on the counter's address),
+    // and keeps the order of its rays.
+    const unsigned long long mask = __ballot(going);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_wave_total[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < SHADE_BLOCK / 64; w++) total += s_wave_total[w];
+        s_base = total ? atomicAdd(W.counts + iter + 1, total) : 0u;
     }
+    __syncthreads();
+    if (!going) return;
+    uint32_t pos = s_base + (uint32_t)lane_rank_in(mask);
+    for (int w = 0; w < wave; w++) pos += s_wave_total[w];
 
-    // the path goes on: save its state and queue the next ray
-    W.color[slot] = new_color;
-    W.seed[slot] = L.seed;
-    W.ior[slot] = L.current_IOR;
     bool inside_default = true;
 #pragma unroll
     for (int i = 0; i < MAX_OVERLAP; i++) inside_default = inside_default && L.in_mat[i] == 0 && L.in_pri[i] == INT_NEG_LIMIT;
     const bool store_inside = track_inside && (inside_stored || !inside_default);
-    W.misc[slot] = make_int2(L.inside_of_count, (L.refraction_bounces & 0x3FFFFFFF) | (store_inside ? (1 << 30) : 0));
     if (store_inside) {
 #pragma unroll
         for (int i = 0; i < MAX_OVERLAP; i++) {
@@ -369,15 +426,13 @@ __global__ __launch_bounds__(64) void ptk_wf_shade(const PtkParams P, int iter) 
             W.inside[(size_t)(MAX_OVERLAP + i) * W.n_slots + slot] = L.in_pri[i];
         }
     }
-    const unsigned long long going = __ballot(true);
-    const int leader = __ffsll((long long)going) - 1;
-    uint32_t base = 0;
-    if ((int)threadIdx.x == leader) base = atomicAdd(W.counts + iter + 1, (uint32_t)__popcll(going));
-    base = (uint32_t)__shfl((int)base, leader);
-    const uint32_t pos = base + (uint32_t)lane_rank_in(going);
     float4* out = W.rays[(iter + 1) & 1];
     out[(size_t)pos * 2] = make_float4(nr.o.x, nr.o.y, nr.o.z, bitsf(slot));
     out[(size_t)pos * 2 + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, 0.0f);
+    float4* sout = W.state[(iter + 1) & 1];
+    sout[(size_t)pos * 2] = new_color;
+    sout[(size_t)pos * 2 + 1] = make_float4(L.seed, L.current_IOR, bitsf((uint32_t)L.inside_of_count),
+                                            bitsf((uint32_t)((L.refraction_bounces & 0x3FFFFFFF) | (store_inside ? (1 << 30) : 0))));
 }
 
 extern "C" hipError_t ptk_wavefront_occupancy(size_t lds_bytes, int* waves_per_cu) {
@@ -391,14 +446,14 @@ extern "C" hipError_t ptk_wavefront_occupancy(size_t lds_bytes, int* waves_per_c
 extern "C" hipError_t ptk_launch_wavefront(const PtkParams* p, int gx, int gy, int n_iter, size_t lds_bytes,
                                            int n_waves, hipEvent_t* ev, hipStream_t stream) {
     const unsigned blocks = (unsigned)gx * (unsigned)gy;
-    hipError_t e = hipMemsetAsync(p->wf.counts, 0, 2 * (PTK_WF_MAX_ITER + 1) * sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(p->wf.counts, 0, 1024, stream);  // counts, heads (and development counters)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ptk_wf_generate, dim3(blocks), dim3(64), 0, stream, *p);
     for (int it = 0; it < n_iter; it++) {
         if (ev) { e = hipEventRecord(ev[2 * it], stream); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL(ptk_wf_traverse, dim3((unsigned)n_waves), dim3(64), lds_bytes, stream, *p, it);
         if (ev) { e = hipEventRecord(ev[2 * it + 1], stream); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL(ptk_wf_shade, dim3(blocks), dim3(64), 0, stream, *p, it);
+        hipLaunchKernelGGL(ptk_wf_shade, dim3((blocks * 64u + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, stream, *p, it);
     }
     return hipGetLastError();
 }
