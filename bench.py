@@ -12,9 +12,13 @@ N > 1 runs under torch.distributed.run, one process per GPU: the scene is replic
 renders its own batch of K samples of the full frame (weak scaling) and the per-GPU accumulation
 images are combined once per batch with an RCCL reduce inside the timed region.
 
-Rank 0 prints one JSON line; see the keys "roofline" (dominant kernel: algorithmic bytes / measured
-kernel time against the 8 TB/s HBM peak) and "cpu_baseline" (the CPU restatement of the shader on
-the host cores, one full-frame dispatch).
+A step is rendered by the wavefront pipeline: one generate launch, then per bounce one traversal
+launch (ptk_wf_traverse, the dominant kernel) and one shading launch.
+
+Rank 0 prints one JSON line; see the keys "roofline" (the traversal kernel: algorithmic bytes of the
+closest-hit searches / its measured launch durations, against the 8 TB/s HBM peak; "step" repeats the
+figure for all bytes of a step over the whole step) and "cpu_baseline" (the CPU restatement of the
+shader on the host cores, a few full-frame dispatches).
 """
 import argparse
 import importlib
@@ -35,15 +39,35 @@ DEPTH, REFRACTION_BOUNCES = 8, 4
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
 
-def algorithmic_bytes(cnt, n_planes_padded, pixels):
-    """Bytes the reference's layout makes one dispatch touch, no cache credit:
-    32 B per box test, 4 B per object id, 32 B per sphere test, 48 B per triangle test (three points),
-    32 B per plane record scanned per ray, the hit record (32 / 32 / 80 B) and 64 B material per
-    resolved hit, 64 B per mesh-socket matrix, 32 B image read+write and 128 B push constants per pixel."""
+def traversal_bytes(cnt, n_planes_padded):
+    """Bytes the reference's layout makes the closest-hit searches of one dispatch touch, no cache
+    credit: 32 B per box test (root included), 4 B per object id, 32 B per sphere test, 48 B per
+    triangle test (three points), 32 B per plane record scanned per ray, 64 B per mesh-socket matrix."""
     c = {k: int(v) for k, v in cnt.items()}
     return (32 * c["box_tests"] + 4 * c["obj_tests"] + 32 * c["sphere_tests"] + 48 * c["tri_tests"]
-            + 32 * n_planes_padded * c["rays"] + 32 * c["hit_sphere"] + 32 * c["hit_plane"] + 80 * c["hit_triangle"]
-            + 64 * c["material_fetch"] + 64 * c["sockets"] + pixels * (32 + 128))
+            + 32 * n_planes_padded * c["rays"] + 64 * c["sockets"])
+
+
+def algorithmic_bytes(cnt, n_planes_padded, pixels):
+    """All bytes of a dispatch: the searches, plus the hit record (32 / 32 / 80 B) and 64 B material per
+    resolved hit, 32 B image read+write and 128 B push constants per pixel."""
+    c = {k: int(v) for k, v in cnt.items()}
+    return (traversal_bytes(cnt, n_planes_padded) + 32 * c["hit_sphere"] + 32 * c["hit_plane"] + 80 * c["hit_triangle"]
+            + 64 * c["material_fetch"] + pixels * (32 + 128))
+
+
+def measured_traffic(workload):
+    """Memory-side bytes per traversal launch from the committed rocprofv3 PMC passes of this same
+    command (FETCH_SIZE and WRITE_SIZE in separate runs), or None when no pass of this workload is on file."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if t.get("workload") != workload:
+        return None
+    return t.get("traverse_bytes_per_launch")
 
 
 def main():
@@ -127,7 +151,9 @@ def main():
     run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t_start
-    kernel_ms = rd.dispatch_history_ms(min(args.steps, 64))
+    n_hist = min(args.steps, 64)
+    kernel_ms = rd.dispatch_history_ms(n_hist)
+    traverse_ms = [rd.dispatch_traverse_ms(back) for back in range(n_hist)]  # per dispatch: one duration per launch
 
     rays_total = rays_local
     if world > 1:
@@ -143,9 +169,17 @@ def main():
             dist.destroy_process_group()
         return
 
-    avg_kernel_ms = float(np.mean(kernel_ms))
-    bytes_per_launch = algorithmic_bytes(cnt, n_planes_padded, pixels * args.steps) / args.steps
-    achieved_gbs = bytes_per_launch / (avg_kernel_ms * 1e-3) / 1e9
+    workload = "sponza_standin_atrium_262144tri_1920x1080_1spp_per_step_depth8_refr4_bvh_xyz_order8"
+    avg_step_ms = float(np.mean(kernel_ms))
+    launches = sum(len(t) for t in traverse_ms)
+    if launches == 0:
+        raise SystemExit("the timed dispatches did not run the wavefront traversal kernel")
+    avg_launch_ms = sum(sum(t) for t in traverse_ms) / launches
+    launches_per_step = launches / n_hist
+    trav_bytes_per_launch = traversal_bytes(cnt, n_planes_padded) / args.steps / launches_per_step
+    achieved_gbs = trav_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    step_bytes = algorithmic_bytes(cnt, n_planes_padded, pixels * args.steps) / args.steps
+    step_gbs = step_bytes / (avg_step_ms * 1e-3) / 1e9
     out = {
         "metric": "Mrays/s (path segments/s) at 1920x1080 Sponza",
         "value": rays_total / elapsed / 1e6,
@@ -160,7 +194,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "sponza_standin_atrium_262144tri_1920x1080_1spp_per_step_depth8_refr4_bvh_xyz_order8",
+            "workload": workload,
             "width": WIDTH, "height": HEIGHT, "triangles": N_TRIANGLES, "max_ray_depth": DEPTH,
             "max_refraction_bounces": REFRACTION_BOUNCES, "rays_per_step": rays_local / args.steps,
             "bvh_nodes": len(disp.packed.bvh) // 32, "bvh_build_s": build_s,
@@ -168,15 +202,18 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "ptk_render_kernel",
+            "kernel": "ptk_wf_traverse",
             "achieved": achieved_gbs,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
-            "traffic": None,
-            "bytes_per_launch": bytes_per_launch,
-            "bytes_per_ray": bytes_per_launch * args.steps / max(rays_local, 1),
-            "kernel_ms_avg": avg_kernel_ms,
+            "traffic": measured_traffic(workload),
+            "bytes_per_launch": trav_bytes_per_launch,
+            "launch_ms_avg": avg_launch_ms,
+            "launches_per_step": launches_per_step,
+            "bytes_per_ray": traversal_bytes(cnt, n_planes_padded) / max(rays_local, 1),
+            "step": {"bytes": step_bytes, "gpu_ms": avg_step_ms, "achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
+                     "bytes_per_ray": step_bytes * args.steps / max(rays_local, 1)},
         },
     }
 
@@ -188,18 +225,22 @@ def main():
 
         cores = min(os.cpu_count() or 1, 16)
         img = np.zeros((HEIGHT, WIDTH, 4), np.float32)
-        win.frame = 0
-        push = wd.push_constant_bytes(scene.camera, win, wd.sample_time(0))
-        c0 = time.perf_counter()
-        res = ob.render(disp.packed, push, img, WIDTH // 8, HEIGHT // 8, nthreads=cores)
-        cpu_s = time.perf_counter() - c0
+        cpu_rays, cpu_s, n_cpu = 0, 0.0, 0
+        while cpu_s < 10.0 and n_cpu < 16:  # bounded sample: full-frame dispatches until ~10 s of CPU work
+            win.frame = n_cpu
+            push = wd.push_constant_bytes(scene.camera, win, wd.sample_time(n_cpu))
+            c0 = time.perf_counter()
+            res = ob.render(disp.packed, push, img, WIDTH // 8, HEIGHT // 8, nthreads=cores)
+            cpu_s += time.perf_counter() - c0
+            cpu_rays += int(res["totals"][0])
+            n_cpu += 1
         out["cpu_baseline"] = {
-            "value": float(res["totals"][0]) / cpu_s / 1e6,
+            "value": cpu_rays / cpu_s / 1e6,
             "unit": "Mrays/s",
             "cores": cores,
             "kind": "port",
-            "sample": "one full 1920x1080 dispatch (1 spp, depth 8) of the same scene and BVH; %.1f s of CPU work" % cpu_s,
-            "ms_per_step": cpu_s * 1e3,
+            "sample": "%d full 1920x1080 dispatches (1 spp each, depth 8) of the same scene and BVH; %.1f s of CPU work" % (n_cpu, cpu_s),
+            "ms_per_step": cpu_s / n_cpu * 1e3,
         }
     print(json.dumps(out))
     if world > 1:
