@@ -92,6 +92,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pta = importlib.import_module("path-tracer_amd")
+    mg = importlib.import_module("path-tracer_amd.multi_gpu")
     wd = pta.work_dispatcher
     scene = pta.scenes.atrium_scene(N_TRIANGLES, seed=7)
     rd = pta.PtkRenderingDevice(local_rank if world > 1 else 0)
@@ -108,7 +109,7 @@ def main():
 
     def sample_index(k):
         # every rank renders its own disjoint set of samples
-        return rank * args.steps + k
+        return mg.sample_index(rank, args.steps, k)
 
     # --- untimed: count the rays and traversal work of exactly the K timed steps (traced kernel variant)
     rd.trace_enable(pta.rendering_device.PTK_TRACE_COUNTERS)
@@ -132,9 +133,8 @@ def main():
         if world > 1:
             # combine the per-GPU accumulators: mean over ranks of each rank's running mean
             rd.image_copy_device(disp.image_buffer, reduce_buf.data_ptr(), reduce_buf.numel() * 4, to_image=False)
-            dist.reduce(reduce_buf, dst=0, op=dist.ReduceOp.SUM)
+            mg.reduce_batch_means(reduce_buf, dst=0)
             if rank == 0:
-                reduce_buf.mul_(1.0 / world)
                 torch.cuda.synchronize()
                 rd.image_copy_device(disp.image_buffer, reduce_buf.data_ptr(), reduce_buf.numel() * 4, to_image=True)
         rd.sync()

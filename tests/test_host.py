@@ -1,0 +1,160 @@
+"""CPU-side checks: byte layouts of the host mirror, the C ABI surface of libptk, failure without the
+library or without a GPU, and the multi-GPU partitioning logic over gloo (world size 2)."""
+import ctypes
+import importlib
+import os
+import re
+import socket
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- byte layouts (pt_work_dispatcher.gd:163-164,656-808) -------------------------------------------
+def test_ceil_snap_is_strictly_greater(pta):
+    cs = pta.work_dispatcher.ceil_snap
+    assert cs(0, 16) == 16 and cs(15, 16) == 16 and cs(16, 16) == 32 and cs(64, 64) == 128 and cs(65, 64) == 128
+
+
+def _small_scene(pta):
+    sc = pta.scene
+    scene = sc.PTScene()
+    red = sc.PTMaterial(albedo=(1.0, 0.0, 0.0))
+    glass = sc.PTMaterial(opacity=0.0, IOR=1.5, dielectric_priority=3)
+    scene.add_object(sc.PTSphere(radius=0.5, material=red))
+    scene.add_object(sc.PTSphere(radius=0.25, material=glass))
+    scene.add_object(sc.PTSphere(radius=0.75, material=red))
+    scene.add_object(sc.PTPlane(normal=(0.0, 1.0, 0.0), distance=-1.0))
+    scene.add_object(sc.PTTriangle(vertex1=(0.0, 0.0, 0.0), vertex2=(1.0, 0.0, 0.0), vertex3=(0.0, 1.0, 0.0), material=glass))
+    scene.camera = sc.PTCamera()
+    return scene, red, glass
+
+
+def test_record_sizes_and_padding(pta):
+    wd = pta.work_dispatcher
+    scene, red, glass = _small_scene(pta)
+    mats = wd.create_materials_byte_array(scene)
+    assert len(mats) == 16 * 64  # 4 materials -> next multiple of 16, 64 bytes each
+    assert len(wd.create_spheres_byte_array(scene)) == 64 * 32
+    planes = wd.create_planes_byte_array(scene)
+    assert len(planes) == 16 * 32 and planes[32:] == bytes(15 * 32)  # padding records are all zero
+    # one 80-byte triangle, 15 padding records of 32 bytes each (pt_work_dispatcher.gd:717-718)
+    assert len(wd.create_triangles_byte_array(scene)) == 80 + 15 * 32
+    assert wd.create_transform_byte_array(scene) == bytes(64)  # no meshes: one zero matrix
+
+
+def test_material_index_rules(pta):
+    """Index 0 is air, 1 the default material, user materials follow from 2 in first-use order
+    (pt_scene.gd:56-59,124-137,310-332)."""
+    wd = pta.work_dispatcher
+    scene, red, glass = _small_scene(pta)
+    assert scene.get_material_index(red) == 2 and scene.get_material_index(glass) == 3
+    assert scene.get_material_index(None) == 1
+    mats = wd.create_materials_byte_array(scene)
+    air = struct.unpack_from("<8f8i", mats, 0)
+    assert air[5] == 0.0 and air[6] == 0.0 and air[7] == 1.0  # opacity 0, reflectivity 0, IOR 1
+    sph = wd.create_spheres_byte_array(scene)
+    assert [struct.unpack_from("<i", sph, 32 * i + 16)[0] for i in range(3)] == [2, 3, 2]
+    tri = wd.create_triangles_byte_array(scene)
+    assert struct.unpack_from("<i", tri, 64)[0] == 3
+    assert pta.scene.make_object_id(5, 3) == 5 + (3 << 24)
+
+
+def test_push_constants_layout(pta):
+    wd = pta.work_dispatcher
+    scene, _, _ = _small_scene(pta)
+    win = wd.PTRenderWindow(render_width=640, render_height=360, max_ray_depth=4, max_refraction_bounces=6,
+                            x_offset=16, y_offset=24, render_mode=2, display_object_count=True)
+    win.frame = 7
+    b = wd.push_constant_bytes(scene.camera, win, 0.0625)
+    assert len(b) == 128
+    ints = struct.unpack_from("<13i", b, 64)
+    assert ints[0] == 1 | 2 | 4 | 8 and ints[1] == 2 and ints[2:5] == (0, 0, 0)
+    assert ints[5:7] == (16, 24) and ints[7:9] == (50, 40) and ints[9:13] == (640, 360, 4, 6)
+    assert struct.unpack_from("<3f", b, 116) == (0.0625, 7.0, 16.0)
+    assert win.work_group_width == 80 and win.work_group_height == 45
+    # the reproducible clock: 16 ms per dispatch, wrapped like fmod(ticks / 1e5, 0.1)
+    assert wd.sample_time(0) == 0.0 and abs(wd.sample_time(1) - 0.00016) < 1e-12 and wd.sample_time(625) < 1e-9
+
+
+def test_texture_id_encoding(pta):
+    sc = pta.scene
+    assert sc.PTProceduralTexture(is_spatial=True).get_texture_id(3) == (2 << 30) ^ 3
+    assert sc.PTSampledTexture().get_texture_id(5) == (1 << 30) ^ 5
+
+
+# ---- the C ABI ---------------------------------------------------------------------------------
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "ptk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pta):
+    names = _declared_functions()
+    assert len(names) >= 20 and "ptk_dispatch" in names and "ptk_bvh_build" in names
+    assert sorted(pta.EXPORTS) == names, "include/ptk.h and the Python binding list different entry points"
+    lib = ctypes.CDLL(pta.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"libptk.so lacks {missing}"
+
+
+def test_fails_loudly_without_library():
+    """No CPU fallback: a missing libptk.so is an error at first use, naming the path."""
+    code = ("import importlib, sys; sys.path.insert(0, %r); p = importlib.import_module('path-tracer_amd');\n"
+            "try:\n    p.PtkRenderingDevice(0)\nexcept p.PtkError as e:\n    print('PtkError', e)\n" % ROOT)
+    env = dict(os.environ, PTK_LIBRARY="/nonexistent/libptk.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert "PtkError" in out.stdout and "/nonexistent/libptk.so" in out.stdout, out.stdout + out.stderr
+
+
+def test_fails_loudly_without_gpu(pta):
+    """With the library but no HIP device, creating a context raises instead of rendering somewhere else."""
+    try:
+        dev = pta.PtkRenderingDevice(0)
+    except pta.PtkError as e:
+        assert "device" in str(e).lower()
+        return
+    dev.close()
+    pytest.skip("a GPU is present")
+
+
+# ---- multi-GPU partitioning over gloo ------------------------------------------------------------
+def test_row_bands_cover_the_image():
+    mg = importlib.import_module("path-tracer_amd.multi_gpu")
+    for rows, world in [(135, 8), (135, 2), (45, 4), (3, 8), (0, 2)]:
+        bands = mg.row_bands(rows, world)
+        assert len(bands) == world and bands[0][0] == 0 and sum(n for _, n in bands) == rows
+        assert all(bands[i][0] + bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+        assert max(n for _, n in bands) - min(n for _, n in bands) <= 1
+    ids = [mg.sample_index(r, 5, k) for r in range(4) for k in range(5)]
+    assert ids == list(range(20))
+
+
+def test_two_rank_partitioning_matches_one_rank(tmp_path):
+    """World size 2 over gloo: tile rows assemble to the one-rank image bit for bit; sample batches
+    average to the mean of the same samples (summation order differs: tolerance 1e-6 absolute)."""
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import dist_worker as dw
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(dw.worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+
+    ob, pta, wd, scene, packed = dw._setup()
+    whole = dw.render_samples(ob, wd, scene, packed, [1])
+    tiles = np.load(tmp_path / "tiles.npy")
+    assert np.array_equal(tiles.view(np.uint32), whole.view(np.uint32))
+    means = [dw.render_samples(ob, wd, scene, packed, [r * dw.STEPS + k for k in range(dw.STEPS)]) for r in range(2)]
+    expect = (means[0].astype(np.float64) + means[1].astype(np.float64)) / 2
+    got = np.load(tmp_path / "batch_mean.npy")
+    assert np.abs(got - expect).max() <= 1e-6
