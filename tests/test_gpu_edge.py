@@ -1,0 +1,99 @@
+"""GPU parity on the edges of the dispatch contract: textures of every kind, image sizes that are not a
+multiple of the 8x8 group, an empty scene, and the cases where the wavefront pipeline hands over to the
+one-kernel renderer.  Same bar as test_gpu_parity: images bit-identical to the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from test_gpu_parity import _compare_image, _run_case, rd, rd_wf  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+def _textured_scene(pta):
+    sc, gm = pta.scene, pta.godot_math
+    rng = np.random.default_rng(11)
+    scene = sc.PTScene()
+    img = rng.random((8, 16, 4), dtype=np.float32)
+    tex_a = sc.PTSampledTexture(image=img)
+    tex_missing = sc.PTSampledTexture(image=None)  # filler grid
+    tex_uv = sc.PTProceduralTexture(texture_path="res://shaders/procedural_textures/checker_board.comp")
+    tex_sp = sc.PTProceduralTexture(texture_path="res://shaders/procedural_textures/checker_board_spatial.comp", is_spatial=True)
+    grey = sc.PTMaterial(albedo=(0.8, 0.8, 0.8))
+    metal = sc.PTMaterial(albedo=(0.9, 0.7, 0.5), metallic=0.9)
+    glass = sc.PTMaterial(opacity=0.0, IOR=1.5)
+    for i, (tex, mat) in enumerate([(tex_a, grey), (tex_missing, grey), (tex_uv, metal), (tex_sp, grey), (None, glass)]):
+        scene.add_object(sc.PTSphere(radius=0.6, material=mat, texture=tex, transform=gm.Transform3D(origin=(-3.0 + 1.5 * i, 0.0, 0.0))))
+    scene.add_object(sc.PTPlane(normal=(0.0, 1.0, 0.0), distance=-0.6, material=grey, texture=tex_sp))
+    scene.add_object(sc.PTTriangle(vertex1=(-4.0, -0.6, -2.0), vertex2=(4.0, -0.6, -2.0), vertex3=(0.0, 3.0, -2.5), material=grey, texture=tex_a))
+    scene.camera = sc.PTCamera(transform=gm.Transform3D.looking_at((0.0, 1.0, 6.0), (0.0, 0.0, 0.0)), fov=50.0)
+    return scene
+
+
+def test_sampled_filler_and_procedural_textures(pta, rd, rd_wf, golden_dir):
+    _run_case(pta, rd, rd_wf, golden_dir, "textured", 320, 184, 6, 4, dispatches=2, scene=_textured_scene(pta))
+
+
+def test_image_not_a_multiple_of_the_group(pta, rd, rd_wf, golden_dir):
+    """100 x 60 pixels under 13 x 8 groups: invocations outside the image compute but never store."""
+    wd = pta.work_dispatcher
+    scene = pta.scenes.load_fixture_scene("sphere_scene1", golden_dir)
+    packed = wd.pack_scene(scene, ob.OracleBvhBuilder(), 8)
+    w, h, gx, gy = 100, 60, 13, 8
+    cpu = np.zeros((h, w, 4), np.float32)
+    disps = []
+    for dev in (rd, rd_wf):
+        d = wd.PTWorkDispatcher(dev)
+        d.create_buffers(w, h, packed=packed)
+        d.load_shader()
+        disps.append((dev, d))
+    try:
+        for k in range(3):
+            win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=4, work_group_width=gx, work_group_height=gy)
+            win.frame = k
+            t = wd.sample_time(k)
+            ob.render(packed, wd.push_constant_bytes(scene.camera, win, t), cpu, gx, gy)
+            for dev, d in disps:
+                d.create_compute_list(win, scene.camera, t, sync=True)
+                _compare_image(f"ragged[{k}]", dev.texture_get_data(d.image_buffer), cpu)
+    finally:
+        for _, d in disps:
+            d.free_rids()
+
+
+def test_empty_scene_is_all_sky(pta, rd, rd_wf, golden_dir):
+    scene = pta.scene.PTScene()
+    scene.camera = pta.scene.PTCamera()
+    _run_case(pta, rd, rd_wf, golden_dir, "empty", 64, 64, 3, 2, dispatches=2, scene=scene)
+
+
+def test_wavefront_hands_over_outside_its_range(pta, rd, golden_dir):
+    """More than 32 bounces, or depth 0: AUTO renders with the one-kernel renderer (same image as the
+    oracle), and a context pinned to the wavefront pipeline reports the dispatch as unsupported."""
+    wd = pta.work_dispatcher
+    scene = pta.scenes.load_fixture_scene("sphere_scene3", golden_dir)
+    packed = wd.pack_scene(scene, ob.OracleBvhBuilder(), 8)
+    w, h = 64, 64
+    dev = pta.PtkRenderingDevice(0)
+    try:
+        d = wd.PTWorkDispatcher(dev)
+        d.create_buffers(w, h, packed=packed)
+        d.load_shader()
+        for depth, bounces in [(40, 4), (0, 4), (8, 4)]:
+            dev.texture_update(d.image_buffer, np.zeros((h, w, 4), np.float32))
+            cpu = np.zeros((h, w, 4), np.float32)
+            win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=depth, max_refraction_bounces=bounces)
+            push = wd.push_constant_bytes(scene.camera, win, wd.sample_time(1))
+            ob.render(packed, push, cpu, w // 8, h // 8)
+            dev.set_renderer(pta.rendering_device.PTK_RENDERER_AUTO)
+            d.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
+            used_wavefront = len(dev.dispatch_traverse_ms(0)) > 0
+            assert used_wavefront == (depth == 8)
+            _compare_image(f"depth{depth}", dev.texture_get_data(d.image_buffer), cpu)
+            if depth != 8:
+                dev.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
+                with pytest.raises(pta.PtkError):
+                    d.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
+        d.free_rids()
+    finally:
+        dev.close()
