@@ -114,6 +114,9 @@ DEV void a6_store(float* base, int i, const A6& a) {
     float* q = base + (size_t)i * 6;
     q[0] = a.p[0]; q[1] = a.p[1]; q[2] = a.p[2]; q[3] = a.s[0]; q[4] = a.s[1]; q[5] = a.s[2];
 }
+DEV float rdlane(float v, int lane) {  // value of v in a lane chosen uniformly for the whole wave
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 DEV A6 a6_shfl(const A6& a, int lane) {
     A6 r;
     for (int i = 0; i < 3; i++) { r.p[i] = __shfl(a.p[i], lane); r.s[i] = __shfl(a.s[i], lane); }
@@ -137,11 +140,13 @@ struct CallOut {
 // .abs().grow(1e-6) (:277); also counts mesh sockets and picks the axis (:279-280).
 __global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls, const int* perm, const float* in_aabb,
                                                  const int* in_kind, int type, int fixed_axis, CallOut* out) {
+    __shared__ float tr[6][64];
     int c = blockIdx.x;
     if (c >= n_calls) return;
     int lane = threadIdx.x;
     Call call = calls[c];
     A6 acc = a6_zero();
+    bool acc_valid = false;  // a6_valid(acc), kept alongside (uniform over the wave)
     int meshes = 0;
     for (int base = call.begin; base < call.end; base += 64) {
         int i = base + lane;
@@ -150,10 +155,74 @@ __global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls,
         int kind = 0;
         if (in) { int id = perm[i]; mine = a6_load(in_aabb, id); kind = in_kind[id]; }
         meshes += __popcll(__ballot(in && kind == 1));
-        int cnt = min(64, call.end - base);
-        for (int j = 0; j < cnt; j++) {
-            A6 b = a6_shfl(mine, j);
-            acc = merge_aabb(acc, b);
+        const int cnt = min(64, call.end - base);
+        const unsigned long long vmask = __ballot(in && a6_valid(mine));
+        int j0 = 0;
+        if (!acc_valid) {
+            // invalid merged with invalid is the zero box; the first valid element replaces it (pt_utils.gd:34-43)
+            if (vmask == 0ull) { acc = a6_zero(); continue; }
+            j0 = __ffsll((long long)vmask) - 1;
+            acc = a6_shfl(mine, j0);
+            acc_valid = true;
+            j0++;
+        } else if (vmask == 0ull) {
+            continue;  // a valid box merged with invalid ones stays as it is
+        }
+        // Fast chain: while the accumulated box stays valid, a step is  e1 = p + s;  p' = min(p, bp);
+        // s' = max(e1, bp + bs) - p'  per axis, in list order (the float merge is not associative, so the
+        // order is kept; what is saved is the validity test of both operands inside every step).  A valid
+        // box has s >= 0 and stays so; it can only turn invalid by becoming non-finite (which then sticks
+        // until the end of the batch) or by all three sizes rounding to zero (checked at every step).
+        // If either happened, the batch is redone with the full merge.
+        float e2x = mine.p[0] + mine.s[0], e2y = mine.p[1] + mine.s[1], e2z = mine.p[2] + mine.s[2];
+        float px = acc.p[0], py = acc.p[1], pz = acc.p[2], sx = acc.s[0], sy = acc.s[1], sz = acc.s[2];
+        bool collapsed = false;
+        if (j0 == 0 && vmask == ~0ull) {
+            // a full batch of valid boxes: the three axes are independent chains, so lanes 0..2 run one
+            // axis each over the batch transposed through LDS (7 operations per element and axis)
+            tr[0][lane] = mine.p[0]; tr[1][lane] = mine.p[1]; tr[2][lane] = mine.p[2];
+            tr[3][lane] = e2x; tr[4][lane] = e2y; tr[5][lane] = e2z;
+            __syncthreads();
+            const int a = lane < 3 ? lane : 0;
+            float p = a == 0 ? px : (a == 1 ? py : pz);
+            float sa = a == 0 ? sx : (a == 1 ? sy : sz);
+            float smin = __builtin_inff();
+#pragma unroll
+            for (int j = 0; j < 64; j++) {
+                const float bp = tr[a][j], fe = tr[3 + a][j];
+                const float e1 = p + sa;
+                p = p < bp ? p : bp;
+                sa = (e1 > fe ? e1 : fe) - p;
+                smin = sa < smin ? sa : smin;
+            }
+            __syncthreads();
+            px = rdlane(p, 0); py = rdlane(p, 1); pz = rdlane(p, 2);
+            sx = rdlane(sa, 0); sy = rdlane(sa, 1); sz = rdlane(sa, 2);
+            // all three sizes zero at one step needs every axis to have reached zero at some step
+            collapsed = rdlane(smin, 0) == 0.0f && rdlane(smin, 1) == 0.0f && rdlane(smin, 2) == 0.0f;
+        } else {
+            for (int j = j0; j < cnt; j++) {
+                if (!((vmask >> j) & 1ull)) continue;
+                const float bx = rdlane(mine.p[0], j), by = rdlane(mine.p[1], j), bz = rdlane(mine.p[2], j);
+                const float fx = rdlane(e2x, j), fy = rdlane(e2y, j), fz = rdlane(e2z, j);
+                const float e1x = px + sx, e1y = py + sy, e1z = pz + sz;
+                px = px < bx ? px : bx; py = py < by ? py : by; pz = pz < bz ? pz : bz;
+                sx = (e1x > fx ? e1x : fx) - px;
+                sy = (e1y > fy ? e1y : fy) - py;
+                sz = (e1z > fz ? e1z : fz) - pz;
+                collapsed = collapsed || (sx == 0.0f && sy == 0.0f && sz == 0.0f);
+            }
+        }
+        const float inf = __builtin_inff();
+        const bool finite = fabsf(px) < inf && fabsf(py) < inf && fabsf(pz) < inf && fabsf(sx) < inf && fabsf(sy) < inf && fabsf(sz) < inf;
+        if (finite && !collapsed) {
+            acc.p[0] = px; acc.p[1] = py; acc.p[2] = pz; acc.s[0] = sx; acc.s[1] = sy; acc.s[2] = sz;
+        } else {
+            for (int j = j0; j < cnt; j++) {
+                A6 b = a6_shfl(mine, j);
+                acc = merge_aabb(acc, b);
+            }
+            acc_valid = a6_valid(acc);
         }
     }
     if (lane == 0) {
