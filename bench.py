@@ -87,15 +87,22 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # Rehearsal on a one-GPU box (PTK_BENCH_REHEARSAL=1): every rank uses GPU 0 and the process group runs
+    # over gloo, which exercises the same control flow (batches, reduce, copy-back, timing) without RCCL.
+    rehearsal = os.environ.get("PTK_BENCH_REHEARSAL") == "1"
+    device_index = 0 if (rehearsal or world == 1) else local_rank
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
 
     pta = importlib.import_module("path-tracer_amd")
     mg = importlib.import_module("path-tracer_amd.multi_gpu")
     wd = pta.work_dispatcher
     scene = pta.scenes.atrium_scene(N_TRIANGLES, seed=7)
-    rd = pta.PtkRenderingDevice(local_rank if world > 1 else 0)
+    rd = pta.PtkRenderingDevice(device_index)
     disp = wd.PTWorkDispatcher(rd)
     disp.set_scene(scene)
     t0 = time.time()
@@ -124,7 +131,7 @@ def main():
 
     reduce_buf = None
     if world > 1:
-        reduce_buf = torch.empty((HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+        reduce_buf = torch.empty((HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{device_index}")
 
     def run_steps(n, first_frame=0):
         for k in range(n):
@@ -157,7 +164,7 @@ def main():
 
     rays_total = rays_local
     if world > 1:
-        t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=f"cuda:{device_index}")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

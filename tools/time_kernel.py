@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pta = importlib.import_module("path-tracer_amd")
 wd = pta.work_dispatcher
-w, h = 1920, 1080
+w, h = (3840, 2160) if os.environ.get("PTK_4K") else (1920, 1080)
 which = sys.argv[1] if len(sys.argv) > 1 else "atrium"
 scene = pta.scenes.atrium_scene(262144, seed=7) if which == "atrium" else pta.scenes.random_spheres_scene(100, 3)
 rd = pta.PtkRenderingDevice(0)
@@ -22,6 +22,9 @@ rd.sync()
 ms = rd.dispatch_history_ms(6)
 tr = rd.dispatch_traverse_ms(0)
 print("traverse launches ms", ["%.3f" % x for x in tr], "sum %.3f" % sum(tr))
+import time
+t0 = time.perf_counter()
 img = rd.texture_get_data(disp.image_buffer)
+readback_ms = (time.perf_counter() - t0) * 1e3
 import zlib
-print(os.environ.get("PTK_LIBRARY", "default"), which, "kernel ms median %.3f" % float(np.median(ms)), "crc %08x" % zlib.crc32(bytes(img)))
+print(os.environ.get("PTK_LIBRARY", "default"), which, "kernel ms median %.3f" % float(np.median(ms)), "crc %08x" % zlib.crc32(bytes(img)), "image read-back %.2f ms" % readback_ms)
