@@ -68,7 +68,11 @@ struct ptk_ctx {
     // wavefront renderer
     int renderer = PTK_RENDERER_AUTO;
     bool wf_ok = false;            // scene has no mesh socket below another mesh socket
-    float4* d_rt_nodes = nullptr;  // nodes with traversal entries in the w words
+    float4* d_blocks = nullptr;    // compiled inner nodes, 256 bytes each (see PtkWavefront)
+    int2* d_sockets = nullptr;
+    float root_box[6] = {0};
+    uint32_t root_entry = 0;
+    uint32_t n_blocks = 0, n_sockets = 0, n_records = 0;
     float4* d_leaf_records = nullptr;  // per object-id slot: the primitive by value (48 bytes)
     void* d_wf = nullptr;          // queues + path state, one allocation
     size_t wf_slots = 0;
@@ -165,7 +169,8 @@ void ptk_destroy(ptk_ctx* ctx) {
     if (ctx->d_spill_t) (void)hipFree(ctx->d_spill_t);
     if (ctx->d_trace_primary) (void)hipFree(ctx->d_trace_primary);
     if (ctx->d_trace_counters) (void)hipFree(ctx->d_trace_counters);
-    if (ctx->d_rt_nodes) (void)hipFree(ctx->d_rt_nodes);
+    if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
+    if (ctx->d_sockets) (void)hipFree(ctx->d_sockets);
     if (ctx->d_leaf_records) (void)hipFree(ctx->d_leaf_records);
     if (ctx->d_wf) (void)hipFree(ctx->d_wf);
     if (ctx->d_wf_spill) (void)hipFree(ctx->d_wf_spill);
@@ -412,7 +417,6 @@ static int validate_scene(ptk_ctx* ctx) {
     // while the subtree of a popped node is processed: all k children are pushed
     // at once, then each is popped with up to k-1 siblings still below it.
     std::vector<uint8_t> visited((size_t)n_nodes, 0);
-    std::vector<uint8_t> rt_nodes(nodes->shadow.begin(), nodes->shadow.begin() + (size_t)n_nodes * 32);
     bool wf_ok = true;
     std::string walk_error;
     int walk_code = PTK_OK;
@@ -423,7 +427,7 @@ static int validate_scene(ptk_ctx* ctx) {
         bool bad(int c, const char* fmt, int a = 0, int b = 0, int d = 0) {
             char buf[256]; snprintf(buf, sizeof buf, fmt, a, b, d); err = buf; code = c; return false;
         }
-        std::vector<uint8_t>& rt; bool& wf_ok;
+        bool& wf_ok;
         bool need(int i, int depth, bool in_mesh, int& out) {
             if (i < 0 || i >= n_nodes) return bad(PTK_E_INVALID, "BVH references node %d outside the buffer (%d nodes)", i, n_nodes);
             if (visited[i]) return bad(PTK_E_INVALID, "BVH node %d is reachable twice (not a tree)", i);
@@ -433,11 +437,9 @@ static int validate_scene(ptk_ctx* ctx) {
             int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
             int x = nv.xform(i);
             if (x >= n_xf) return bad(PTK_E_INVALID, "node %d: transform index %d out of range (%d)", i, x, n_xf);
-            if (x >= 0) {
-                // a mesh socket: at world level the traversal entry names the socket itself
-                if (in_mesh) wf_ok = false;
-                else { uint32_t e = 0x7F000000u | (uint32_t)i; memcpy(rt.data() + (size_t)i * 32 + 12, &e, 4); }
-            }
+            // (an all-zero root, the empty tree, has transform index 0 and child index 0: harmless)
+            if (x >= 0 && idx < 0) return bad(PTK_E_INVALID, "node %d: a mesh socket (transform index %d) must have a child node", i, x);
+            if (x >= 0 && in_mesh) wf_ok = false;  // a mesh socket below another: one-kernel renderer only
             const bool child_in_mesh = in_mesh || x >= 0;
             if (idx <= 0) {
                 int base = std::abs(idx) - 1;
@@ -462,18 +464,62 @@ static int validate_scene(ptk_ctx* ctx) {
             out = best;
             return true;
         }
-    } walker{nv, idp, visited, n_nodes, n_ids, n_sph, n_tri, n_xf, walk_error, walk_code, rt_nodes, wf_ok};
+    } walker{nv, idp, visited, n_nodes, n_ids, n_sph, n_tri, n_xf, walk_error, walk_code, wf_ok};
     int result = 0;
     if (!walker.need(0, 0, false, result)) return fail(ctx, walk_code, "%s", walk_error.c_str());
-    if (n_nodes > 0x00FFFFFF) wf_ok = false;
-    ctx->wf_ok = wf_ok;
-    if (ctx->d_rt_nodes) { (void)hipFree(ctx->d_rt_nodes); ctx->d_rt_nodes = nullptr; }
-    // padded: the traversal kernel fetches all eight child slots of a node unconditionally
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_rt_nodes, rt_nodes.size() + 32 * PTK_MAX_WIDTH));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_rt_nodes, rt_nodes.data(), rt_nodes.size(), hipMemcpyHostToDevice, ctx->stream));
     ctx->stack_need = std::max(1, result + 1);
     if (ctx->stack_need > 1024)
         return fail(ctx, PTK_E_UNSUPPORTED, "BVH can need %d stack entries; the reference's traversal stack holds 1024", ctx->stack_need);
+    if (n_nodes > 0x00FFFFFF) wf_ok = false;
+    ctx->wf_ok = wf_ok;
+
+    // Compile the inner nodes for the traversal kernel (layout in PtkWavefront): block b holds the boxes
+    // and entries of one inner node's children; blocks are numbered parent first, depth first.
+    std::vector<float> blocks;
+    std::vector<int32_t> sockets;
+    if (wf_ok) {
+        struct Compiler {
+            const NodeView& nv; std::vector<float>& blocks; std::vector<int32_t>& sockets;
+            uint32_t compile(int i, bool in_mesh) {
+                const int id = nv.node_id(i);
+                const int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
+                const int x = nv.xform(i);
+                if (idx <= 0) return (uint32_t)id;  // leaf
+                if (x >= 0 && !in_mesh) {           // world-level socket: its child is the mesh's root
+                    const uint32_t child = compile(idx, true);
+                    const int sidx = (int)(sockets.size() / 2);
+                    sockets.push_back((int32_t)child);
+                    sockets.push_back(x);
+                    return 0x7F000000u | (uint32_t)sidx;
+                }
+                const size_t b = blocks.size() / 64;
+                blocks.resize(blocks.size() + 64, 0.0f);
+                for (int l = 0; l < size; l++) {
+                    float box[8];
+                    memcpy(box, nv.p + (size_t)(idx + l) * 32, 32);
+                    const uint32_t e = compile(idx + l, in_mesh || x >= 0);
+                    float* blk = blocks.data() + b * 64;  // (re-read: compile() may have grown the vector)
+                    blk[0 + l] = box[0]; blk[8 + l] = box[1]; blk[16 + l] = box[2];
+                    blk[24 + l] = box[4]; blk[32 + l] = box[5]; blk[40 + l] = box[6];
+                    memcpy(blk + 48 + l, &e, 4);
+                }
+                return (uint32_t)b | ((uint32_t)size << 24);
+            }
+        } compiler{nv, blocks, sockets};
+        ctx->root_entry = compiler.compile(0, false);
+        memcpy(ctx->root_box, nv.p, 12);
+        memcpy(ctx->root_box + 3, nv.p + 16, 12);
+        if (blocks.size() / 64 > 0x00FFFFFF) ctx->wf_ok = false;
+    }
+    ctx->n_blocks = (uint32_t)(blocks.size() / 64);
+    ctx->n_sockets = (uint32_t)(sockets.size() / 2);
+    ctx->n_records = (uint32_t)std::max(n_ids, 0);
+    if (ctx->d_blocks) { (void)hipFree(ctx->d_blocks); ctx->d_blocks = nullptr; }
+    if (ctx->d_sockets) { (void)hipFree(ctx->d_sockets); ctx->d_sockets = nullptr; }
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_blocks, std::max<size_t>(256, blocks.size() * 4)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sockets, std::max<size_t>(8, sockets.size() * 4)));
+    if (!blocks.empty()) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blocks, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (!sockets.empty()) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sockets, sockets.data(), sockets.size() * 4, hipMemcpyHostToDevice, ctx->stream));
 
     // leaf records: what a leaf tests for object-id slot i, by value, so the traversal kernel reads a
     // leaf's primitives from consecutive addresses without going through the id table first
@@ -603,7 +649,8 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     P.use_emission = ctx->use_emission;
 
     // traversal stack: an LDS window per lane plus a global spill column for deeper entries
-    const int kLdsWindow = 32;
+    int kLdsWindow = 32;
+    if (const char* w = getenv("PTK_LDS_WINDOW")) kLdsWindow = std::max(8, std::min(64, atoi(w)));  // tuning aid
     const int need = ctx->stack_need;
     P.lds_cap = std::min(need, kLdsWindow);
     const size_t lanes = (size_t)groups_x * groups_y * 64;
@@ -694,7 +741,12 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         P.wf.inside = (int*)base;
         P.wf.n_slots = (uint32_t)n_slots;
         P.wf.tiles_x = groups_x;
-        P.wf.rt_nodes = ctx->d_rt_nodes;
+        P.wf.blocks = ctx->d_blocks;
+        P.wf.sockets = ctx->d_sockets;
+        memcpy(P.wf.root_min, ctx->root_box, 12);
+        memcpy(P.wf.root_max, ctx->root_box + 3, 12);
+        P.wf.root_entry = ctx->root_entry;
+        P.wf.n_blocks = ctx->n_blocks; P.wf.n_sockets = ctx->n_sockets; P.wf.n_records = ctx->n_records;
         P.wf.leaf_records = ctx->d_leaf_records;
     }
     // persistent traversal waves: as many as fit on the device at once
@@ -728,6 +780,16 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     ctx->dispatch_count++;
     return PTK_OK;
 }
+
+#ifdef PTK_CHECKED
+// development build only: error words left by a traversal kernel compiled with index checks
+int ptk_debug_wf_check(ptk_ctx* ctx, unsigned* out4) {
+    if (!ctx || !ctx->d_wf) return PTK_E_STATE;
+    HIP_TRY(ctx, hipMemcpyAsync(out4, (uint8_t*)ctx->d_wf + 800, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTK_OK;
+}
+#endif
 
 #ifdef PTK_ROUND_STATS
 // development build only: round counters of the traversal kernel (zeroed with the queue heads every dispatch)

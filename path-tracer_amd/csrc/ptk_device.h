@@ -52,7 +52,16 @@ struct PtkWavefront {
     int* inside;       // [10][n_slots]: in_mat[0..4], in_pri[0..4]
     uint32_t n_slots;  // groups_x * groups_y * 64
     int tiles_x;
-    const float4* rt_nodes;  // node buffer whose w words hold the traversal entry of each node
+    // Inner nodes compiled for the traversal kernel: one 256-byte block (16 float4) per inner node,
+    // holding its eight child slots as planes: minx[8], miny[8], minz[8], maxx[8], maxy[8], maxz[8],
+    // entry[8], 8 spare words.  An entry is what the traversal visits next: block index | child
+    // count << 24 for an inner child, the leaf's packed node id (negative) for a leaf, or
+    // 0x7F000000 | socket index for a mesh socket met at world level.
+    const float4* blocks;
+    const int2* sockets;     // per world-level mesh socket: {entry of the mesh's root, transform index}
+    float root_min[3], root_max[3];
+    uint32_t root_entry;
+    uint32_t n_blocks, n_sockets, n_records;  // array lengths (checked builds)
     const float4* leaf_records;  // 3 float4 per object-id slot: the primitive a leaf tests, by value
 };
 

@@ -228,13 +228,16 @@ struct Stack {
     int lds_cap;
     int lane;
 };
+// Entries past the LDS window go to the global column.  The host sizes the column from the deepest
+// stack the bound BVH can produce; without a column (null) deeper entries are dropped rather than
+// written through a null pointer.
 PTK_DEV void st_write(const Stack& s, int i, int v) {
     if (i < s.lds_cap) s.lds[i * 64 + s.lane] = v;
-    else s.spill[(size_t)(i - s.lds_cap) * s.spill_stride] = v;
+    else if (s.spill) s.spill[(size_t)(i - s.lds_cap) * s.spill_stride] = v;
 }
 PTK_DEV int st_read(const Stack& s, int i) {
     if (i < s.lds_cap) return s.lds[i * 64 + s.lane];
-    return s.spill[(size_t)(i - s.lds_cap) * s.spill_stride];
+    return s.spill ? s.spill[(size_t)(i - s.lds_cap) * s.spill_stride] : 0;
 }
 
 // Closest hit over planes + BVH, :1200-1320 with :1115-1198 folded into one loop.

@@ -68,7 +68,6 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
 
     const uint32_t count = __builtin_amdgcn_readfirstlane(W.counts[iter]);
     const float4* __restrict__ rq = W.rays[iter & 1];
-    const float4* __restrict__ N = W.rt_nodes;
     uint32_t c_next = 0, c_end = 0;  // this wave's claimed queue range
     bool exhausted = count == 0;
 
@@ -133,9 +132,10 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
                     for (int i = 0; i < P.n_live_planes; ++i) hit_plane(P, ray, h, P.live_planes[i], -1);
                     inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
                     neg = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
-                    const float4 rmin = N[0], rmax = N[1];
+                    const float4 rmin = make_float4(W.root_min[0], W.root_min[1], W.root_min[2], 0.0f);
+                    const float4 rmax = make_float4(W.root_max[0], W.root_max[1], W.root_max[2], 0.0f);
                     const float root_hit = hit_aabb_bl(rmin, rmax, ray.o, inv, neg, ray.start, ray.end);
-                    cur = in_range(root_hit, ray.start, ray.end) ? fbits(rmin.w) : ENTRY_NONE;
+                    cur = in_range(root_hit, ray.start, ray.end) ? W.root_entry : ENTRY_NONE;
                     sp = 0;
                     in_mesh = false;
                     cur_xf = -1;
@@ -153,12 +153,21 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
             // ---- inner round ----
             PTK_STAT(2, 1); PTK_STAT(3, __popcll(mi)); PTK_STAT(4, __popcll(__ballot(is_inner && (cur & 0xFF000000u) == SOCKET_MARK)));
             if (is_inner) {
+#ifdef PTK_CHECKED
+                {
+                    const bool is_sock = (cur & 0xFF000000u) == SOCKET_MARK;
+                    const uint32_t ix = cur & 0x00FFFFFFu;
+                    const bool bad = is_sock ? ix >= W.n_sockets : (ix >= W.n_blocks || (cur >> 24) > 8u || sp < 0 || sp > 1024);
+                    if (bad) { atomicOr(W.counts + 200, 1u); W.counts[201] = cur; W.counts[202] = (uint32_t)sp; }
+                }
+                if (((cur & 0xFF000000u) == SOCKET_MARK) ? (cur & 0x00FFFFFFu) >= W.n_sockets : (cur & 0x00FFFFFFu) >= W.n_blocks) {
+                    cur = ENTRY_NONE; sp = 0; in_mesh = false;
+                } else
+#endif
                 if ((cur & 0xFF000000u) == SOCKET_MARK) {
                     // world level: enter the mesh (:1286-1313); its root is the next node
-                    const int self = (int)(cur & 0x00FFFFFFu);
-                    const float4 smin = P.nodes[(size_t)self * 2], smax = P.nodes[(size_t)self * 2 + 1];
-                    const int node_index = bfe_i((int)fbits(smin.w), 0, 24);
-                    const int xf = (int)fbits(smax.w);
+                    const int2 sock = W.sockets[cur & 0x00FFFFFFu];
+                    const int xf = sock.y;
                     const m44 M = load_xform(P, xf);
                     w_o = ray.o; w_d = ray.d; w_start = ray.start;
                     const f3 unnorm = mul_mv(M, ray.d, 0.0f);
@@ -173,50 +182,60 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
                     sub_base = sp;
                     cur_xf = xf;
                     in_mesh = true;
-                    cur = fbits(N[(size_t)node_index * 2].w);
+                    cur = (uint32_t)sock.x;
                 } else {
-                    const int node_index = bfe_i((int)cur, 0, 24);
-                    const int node_size = iabs(bfe_i((int)cur, 24, 8));
-                    // all eight child slots are fetched with constant offsets (the node buffer copy is
-                    // padded, slots past node_size are ignored) before any of them is used
-                    const float4* __restrict__ cb = N + (size_t)node_index * 2;
-                    float4 bmin[PTK_MAX_WIDTH], bmax[PTK_MAX_WIDTH];
+                    const int node_size = (int)(cur >> 24);
+                    // the node's block: eight child slots as planes (minx[8] .. maxz[8], entry[8]), all
+                    // fetched before any is used; slots past node_size hold zeros and are ignored
+                    const float4* __restrict__ cb = W.blocks + (size_t)(cur & 0x00FFFFFFu) * 16;
+                    float4 q[14];
 #pragma unroll
-                    for (int l = 0; l < PTK_MAX_WIDTH; l++) {
-                        bmin[l] = cb[2 * l];
-                        bmax[l] = cb[2 * l + 1];
-                    }
+                    for (int k = 0; k < 14; k++) q[k] = cb[k];
                     __builtin_amdgcn_sched_barrier(0);
-                    const v2f oxy = {ray.o.x, ray.o.y}, ixy = {inv.x, inv.y};
                     const bool nx = (neg & 1) != 0, ny = (neg & 2) != 0, nz = (neg & 4) != 0;
                     // a NaN in the ray's own range (singular mesh transform) fails in_range for every box
                     const bool range_ok = ray.start == ray.start && ray.end == ray.end;
                     // key = bits of the entry distance t (t >= +0, so unsigned integer order is float
                     // order); rejected children get the bits of +inf, which no accepted t reaches
                     uint32_t key[PTK_MAX_WIDTH];
+                    uint32_t ent[PTK_MAX_WIDTH];
                     int added = 0;
 #pragma unroll
-                    for (int l = 0; l < PTK_MAX_WIDTH; l++) {
-                        // hit_AABB (:670-689): per axis t0 = (min - o) * inv, t1 = (max - o) * inv, the
-                        // arithmetic swap when inv < 0, then start = max, end = min.  start and end are
-                        // never NaN and only move inwards, so testing end <= start once after the last
-                        // axis equals the shader's three early returns, and a box that passes has its t
-                        // inside [ray.start, ray.end] already.
-                        const v2f lo = {bmin[l].x, bmin[l].y}, hi = {bmax[l].x, bmax[l].y};
-                        const v2f t0 = (lo - oxy) * ixy, t1 = (hi - oxy) * ixy;
-                        const v2f sw = t0 + t1, sb = sw - t1, sc = sw - sb;
-                        const float t0z = (bmin[l].z - ray.o.z) * inv.z, t1z = (bmax[l].z - ray.o.z) * inv.z;
-                        const float swz = t0z + t1z, sbz = swz - t1z, scz = swz - sbz;
-                        float start = ray.start, end = ray.end;
-                        start = __builtin_fmaxf(start, nx ? sc.x : t0.x);
-                        end = __builtin_fminf(end, nx ? sb.x : t1.x);
-                        start = __builtin_fmaxf(start, ny ? sc.y : t0.y);
-                        end = __builtin_fminf(end, ny ? sb.y : t1.y);
-                        start = __builtin_fmaxf(start, nz ? scz : t0z);
-                        end = __builtin_fminf(end, nz ? sbz : t1z);
-                        const bool acc = (l < node_size) && (end > start) && range_ok;
-                        key[l] = acc ? (fbits(start) & 0x7FFFFFFFu) : 0x7F800000u;
-                        added += acc ? 1 : 0;
+                    for (int c = 0; c < PTK_MAX_WIDTH / 2; c++) {
+                        // hit_AABB (:670-689) for children 2c and 2c+1 side by side in packed fp32:
+                        // per axis t0 = (min - o) * inv, t1 = (max - o) * inv, the arithmetic swap when
+                        // inv < 0, then start = max, end = min.  start and end are never NaN and only
+                        // move inwards, so testing end <= start once after the last axis equals the
+                        // shader's three early returns, and a box that passes has its t inside
+                        // [ray.start, ray.end] already.
+                        const int h4 = c >> 1;         // which float4 of the plane
+                        const bool hi2 = (c & 1) != 0;  // .zw or .xy
+#define PTK_PAIR(v) (hi2 ? v2f{(v).z, (v).w} : v2f{(v).x, (v).y})
+                        const v2f lox = PTK_PAIR(q[0 + h4]), loy = PTK_PAIR(q[2 + h4]), loz = PTK_PAIR(q[4 + h4]);
+                        const v2f hix = PTK_PAIR(q[6 + h4]), hiy = PTK_PAIR(q[8 + h4]), hiz = PTK_PAIR(q[10 + h4]);
+                        const v2f en = PTK_PAIR(q[12 + h4]);
+#undef PTK_PAIR
+                        const v2f t0x = (lox - ray.o.x) * inv.x, t1x = (hix - ray.o.x) * inv.x;
+                        const v2f t0y = (loy - ray.o.y) * inv.y, t1y = (hiy - ray.o.y) * inv.y;
+                        const v2f t0z = (loz - ray.o.z) * inv.z, t1z = (hiz - ray.o.z) * inv.z;
+                        const v2f swx = t0x + t1x, sbx = swx - t1x, scx = swx - sbx;
+                        const v2f swy = t0y + t1y, sby = swy - t1y, scy = swy - sby;
+                        const v2f swz = t0z + t1z, sbz = swz - t1z, scz = swz - sbz;
+#pragma unroll
+                        for (int e = 0; e < 2; e++) {
+                            const int l = 2 * c + e;
+                            float start = ray.start, end = ray.end;
+                            start = __builtin_fmaxf(start, nx ? scx[e] : t0x[e]);
+                            end = __builtin_fminf(end, nx ? sbx[e] : t1x[e]);
+                            start = __builtin_fmaxf(start, ny ? scy[e] : t0y[e]);
+                            end = __builtin_fminf(end, ny ? sby[e] : t1y[e]);
+                            start = __builtin_fmaxf(start, nz ? scz[e] : t0z[e]);
+                            end = __builtin_fminf(end, nz ? sbz[e] : t1z[e]);
+                            const bool acc = (l < node_size) && (end > start) && range_ok;
+                            key[l] = acc ? (fbits(start) & 0x7FFFFFFFu) : 0x7F800000u;
+                            ent[l] = fbits(en[e]);
+                            added += acc ? 1 : 0;
+                        }
                     }
                     // rank = number of children the shader's selection loop (:1157-1178) would take
                     // earlier: smaller t, or equal t in a lower slot.  For j < l, u = 1 iff child l is
@@ -243,7 +262,7 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
 #pragma unroll
                         for (int l = 0; l < PTK_MAX_WIDTH; l++) {
                             const int rank = l - dn[l] + up[l];
-                            lds_lane[((key[l] != 0x7F800000u) ? top - rank : S.lds_cap) * 64] = (int)fbits(bmin[l].w);
+                            lds_lane[((key[l] != 0x7F800000u) ? top - rank : S.lds_cap) * 64] = (int)ent[l];
                         }
                         if (added > 0) cur = (uint32_t)lds_lane[top * 64];
                     } else {
@@ -251,8 +270,8 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
                         for (int l = 0; l < PTK_MAX_WIDTH; l++) {
                             const int rank = l - dn[l] + up[l];
                             if (key[l] != 0x7F800000u) {
-                                if (rank == 0) cur = fbits(bmin[l].w);
-                                else st_write(S, top - rank, (int)fbits(bmin[l].w));
+                                if (rank == 0) cur = ent[l];
+                                else st_write(S, top - rank, (int)ent[l]);
                             }
                         }
                     }
@@ -283,6 +302,12 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
             }
             // leaf records: {A.xyz | centre.xyz, object id}, {B.xyz | radius, -}, {C.xyz, -}, stored in
             // object-id-slot order, so a leaf's objects are contiguous and need no id lookup first
+#ifdef PTK_CHECKED
+            if (is_leaf && node_size > 0 && (base < 0 || (uint32_t)(base + node_size) > W.n_records)) {
+                atomicOr(W.counts + 200, 2u); W.counts[203] = cur;
+                node_size = 0;
+            }
+#endif
             const float4* __restrict__ rec = W.leaf_records + (size_t)base * 3;
             for (int k = 0;; k++) {
                 const bool go = k < node_size;

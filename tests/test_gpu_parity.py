@@ -161,13 +161,14 @@ def test_random_spheres_10k(pta, rd, rd_wf, golden_dir):
 
 
 # ---- size-independent properties at full BASELINE sizes ------------------------------------------
-def test_full_size_tiles_equal_whole(pta, rd, rd_wf, golden_dir):
-    """1920x1080: rendering the frame as four tiles (image_offset push constants) gives the same image
-    as one dispatch, bit for bit (the seed depends only on absolute pixel coordinates and time)."""
+@pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
+def test_full_size_tiles_equal_whole(pta, rd, rd_wf, golden_dir, w, h):
+    """Full BASELINE sizes (1080p and 4K): rendering the frame as four tiles (image_offset push
+    constants) gives the same image as one dispatch, bit for bit (the seed depends only on absolute
+    pixel coordinates and time)."""
     wd = pta.work_dispatcher
     scene = pta.scenes.load_fixture_scene("benchmark_random_scene", golden_dir)
     packed = wd.pack_scene(scene, ob.OracleBvhBuilder(), 8)
-    w, h = 1920, 1080
     disp = wd.PTWorkDispatcher(rd)
     disp.create_buffers(w, h, packed=packed)
     disp.load_shader()
@@ -180,7 +181,8 @@ def test_full_size_tiles_equal_whole(pta, rd, rd_wf, golden_dir):
     assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
     rd.texture_update(disp.image_buffer, np.zeros((h, w, 4), np.float32))
     gx, gy = w // 8, h // 8
-    for (ox, oy, nx, ny) in [(0, 0, 120, 67), (120, 0, gx - 120, 67), (0, 67, 120, gy - 67), (120, 67, gx - 120, gy - 67)]:
+    sx, sy = gx // 2, gy // 2 - 1  # an uneven split
+    for (ox, oy, nx, ny) in [(0, 0, sx, sy), (sx, 0, gx - sx, sy), (0, sy, sx, gy - sy), (sx, sy, gx - sx, gy - sy)]:
         tile = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=8, max_refraction_bounces=4,
                                  x_offset=ox * 8, y_offset=oy * 8, work_group_width=nx, work_group_height=ny)
         tile.frame = 0
