@@ -25,6 +25,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int SHADE_BLOCK = 512;    // threads per shading block (one queue reservation per block)
 constexpr uint32_t WF_CHUNK = 64;  // rays a wave claims from the queue per atomic
+#ifndef PTK_WF_VOTE_INNER
+#define PTK_WF_VOTE_INNER(ni, nl) ((ni) >= (nl))  // which kind of round runs next: the larger group's
+#endif
 #ifndef PTK_WF_REFILL
 #define PTK_WF_REFILL 12           // lanes without work that make the wave run a refill round
 #endif
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
         }
 
         bool refill = false;
-        if (__popcll(mi) >= __popcll(ml)) {
+        if (PTK_WF_VOTE_INNER(__popcll(mi), __popcll(ml))) {
             // ---- inner round ----
             PTK_STAT(2, 1); PTK_STAT(3, __popcll(mi)); PTK_STAT(4, __popcll(__ballot(is_inner && (cur & 0xFF000000u) == SOCKET_MARK)));
             if (is_inner) {
