@@ -20,7 +20,7 @@ for mode in (1, 2):
     win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=4, max_refraction_bounces=2)
     win.frame = 1
     disp.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
-    if mode == 2:
+    if mode == 2 and hasattr(rd.lib, "ptk_debug_wf_check"):
         out = (C.c_uint * 4)()
         rd.lib.ptk_debug_wf_check.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
         rc = rd.lib.ptk_debug_wf_check(rd.ctx, out)
