@@ -154,6 +154,13 @@ int ptk_set_renderer(ptk_ctx* ctx, int renderer);
  * dispatch used the one-kernel renderer); ms needs room for that many. */
 int ptk_dispatch_traverse_ms(ptk_ctx* ctx, int back, float* ms, int capacity, int* n_launches);
 
+/* How often the library had to re-validate the bound scene and rebuild its derived structures
+ * (full_validations), and how many ptk_buffer_update calls it absorbed by patching them in place
+ * (patched_updates): the reference's incremental edits (pt_renderer.gd:664-788: single records, boxes
+ * of dirty BVH nodes) are patched; a change of node ids, transform indices or the object-id table
+ * makes the next dispatch rebuild.  No counterpart in the reference. */
+int ptk_update_stats(ptk_ctx* ctx, long long* full_validations, long long* patched_updates);
+
 /* Multi-GPU glue; no counterpart in the reference, which renders on one device.  Copies the rgba32f
  * image to (to_image = 0) or from (to_image = 1) a device pointer owned by the caller on the same GPU
  * (e.g. the torch tensor handed to an RCCL reduce / gather), without a trip through host memory. */

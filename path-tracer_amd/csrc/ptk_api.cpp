@@ -73,6 +73,11 @@ struct ptk_ctx {
     float root_box[6] = {0};
     uint32_t root_entry = 0;
     uint32_t n_blocks = 0, n_sockets = 0, n_records = 0;
+    // host mirrors and maps of the derived structures, for patching them on buffer_update
+    std::vector<float> h_blocks, h_leaf_records;
+    std::vector<int32_t> node_slot;  // node index -> block * 8 + child slot holding its box, -1 if none
+    std::vector<int32_t> tri_slot, sph_slot;  // primitive index -> object-id slot holding its record, -1 if none
+    long long full_validations = 0, patched_updates = 0;
     float4* d_leaf_records = nullptr;  // per object-id slot: the primitive by value (48 bytes)
     void* d_wf = nullptr;          // queues + path state, one allocation
     size_t wf_slots = 0;
@@ -117,6 +122,8 @@ static Object* bound_buffer(ptk_ctx* ctx, int set, int binding) {
     if (it == ctx->bound.end()) return nullptr;
     return find(ctx, it->second, Kind::Buffer);
 }
+
+static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, const std::vector<uint8_t>& before);
 
 extern "C" {
 
@@ -252,11 +259,15 @@ int ptk_buffer_update(ptk_ctx* ctx, uint64_t buffer, size_t offset, const void* 
     if (!bytes || offset > o->nbytes || nbytes > o->nbytes - offset)
         return fail(ctx, PTK_E_INVALID, "update of %zu bytes at %zu exceeds buffer of %zu bytes", nbytes, offset, o->nbytes);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const std::vector<uint8_t> before(o->shadow.begin() + offset, o->shadow.begin() + offset + nbytes);
     memcpy(o->shadow.data() + offset, bytes, nbytes);
     // stream-ordered after earlier dispatches; the source is the shadow copy, which outlives the call
     HIP_TRY(ctx, hipMemcpyAsync((uint8_t*)o->dev + offset, o->shadow.data() + offset, nbytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->dirty = true;
+    const int patched = patch_derived(ctx, o, offset, nbytes, before);
+    if (patched < 0) { ctx->dirty = true; return patched; }
+    if (patched == 0) ctx->dirty = true;
+    else ctx->patched_updates++;
     return PTK_OK;
 }
 
@@ -385,6 +396,108 @@ inline int sext(int v, int off, int bits) { return ((int)((uint32_t)v << (32 - o
 
 }  // namespace
 
+// Planes with a non-zero normal, in index order (the others can never be hit, ray_tracer.comp:859).
+static int refresh_live_planes(ptk_ctx* ctx, Object* pln) {
+    const int n_pln = (int)(pln->nbytes / 32);
+    std::vector<int> live;
+    for (int i = 0; i < n_pln; i++) {
+        float nrm[3];
+        memcpy(nrm, pln->shadow.data() + (size_t)i * 32, 12);
+        if (!(nrm[0] == 0.0f && nrm[1] == 0.0f && nrm[2] == 0.0f)) live.push_back(i);
+    }
+    if (ctx->d_live_planes) { (void)hipFree(ctx->d_live_planes); ctx->d_live_planes = nullptr; }
+    ctx->n_live_planes = (int)live.size();
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_live_planes, std::max<size_t>(4, live.size() * 4)));
+    if (!live.empty()) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_live_planes, live.data(), live.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTK_OK;
+}
+
+// The incremental edit path (pt_renderer.gd:664-788 updates single records and the boxes of dirty BVH
+// nodes with rd.buffer_update).  When the derived structures are current and an update keeps the tree's
+// topology, they are patched in place instead of being rebuilt: leaf records of the touched primitives,
+// child boxes of the touched nodes, the live-plane list.  Returns 1 if the update was absorbed, 0 if
+// the next dispatch has to validate and rebuild everything, negative on error.  `before` holds the
+// bytes the update replaced.
+static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, const std::vector<uint8_t>& before) {
+    if (ctx->dirty) return 0;
+    if (bound_buffer(ctx, o->set, o->binding) != o) return 1;  // not what the kernels read
+    Object* mats = bound_buffer(ctx, PTK_SET_OBJECT, 0);
+    const int n_mats = mats ? (int)(mats->nbytes / 64) : 0;
+    const size_t kMaxPatched = 4096;  // beyond this many records a rebuild is the cheaper way
+    auto records = [&](size_t rec_bytes, size_t& first, size_t& last) {
+        first = offset / rec_bytes;
+        last = (offset + nbytes + rec_bytes - 1) / rec_bytes;  // exclusive
+        last = std::min(last, o->nbytes / rec_bytes);
+    };
+    if (o->set == PTK_SET_OBJECT && o->binding == 0) return 1;  // materials: nothing is derived from their contents
+    if (o->set == PTK_SET_TRANSFORM || o->set == PTK_SET_TRIANGLE || o->set == PTK_SET_TEXTURE) return 1;
+    if (o->set == PTK_SET_OBJECT && o->binding == 2) {  // planes
+        size_t a, b;
+        records(32, a, b);
+        for (size_t i = a; i < b; i++) {
+            int32_t m; memcpy(&m, o->shadow.data() + i * 32 + 16, 4);
+            if (m < 0 || m >= n_mats) return 0;  // let validation report it
+        }
+        int r = refresh_live_planes(ctx, o);
+        return r == PTK_OK ? 1 : r;
+    }
+    if (o->set == PTK_SET_OBJECT && (o->binding == 1 || o->binding == 3)) {  // spheres, triangles
+        const bool tri = o->binding == 3;
+        const size_t rec = tri ? 80 : 32;
+        size_t a, b;
+        records(rec, a, b);
+        if (b - a > kMaxPatched) return 0;
+        const std::vector<int32_t>& slot_of = tri ? ctx->tri_slot : ctx->sph_slot;
+        for (size_t i = a; i < b; i++) {
+            int32_t m; memcpy(&m, o->shadow.data() + i * rec + (tri ? 64 : 16), 4);
+            if (m < 0 || m >= n_mats) return 0;
+            if (i >= slot_of.size()) return 0;
+            const int32_t slot = slot_of[i];
+            if (slot == -1) continue;  // not in any leaf
+            if (slot < 0) return 0;    // in several leaves: rebuild
+            float* r = ctx->h_leaf_records.data() + (size_t)slot * 12;
+            const uint8_t* p = o->shadow.data() + i * rec;
+            if (tri) { memcpy(r + 0, p + 0, 12); memcpy(r + 4, p + 16, 12); memcpy(r + 8, p + 32, 12); }
+            else { memcpy(r + 0, p, 12); memcpy(r + 4, p + 12, 4); }
+            HIP_TRY(ctx, hipMemcpyAsync((float*)ctx->d_leaf_records + (size_t)slot * 12, r, 48, hipMemcpyHostToDevice, ctx->stream));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return 1;
+    }
+    if (o->set == PTK_SET_BVH && o->binding == 0) {  // nodes: boxes may move, ids and transform indices may not
+        size_t a, b;
+        records(32, a, b);
+        if (b - a > kMaxPatched || !ctx->wf_ok) return 0;
+        for (size_t i = a; i < b; i++) {
+            const size_t lo = std::max(offset, i * 32), hi = std::min(offset + nbytes, i * 32 + 32);
+            uint8_t old_rec[32];
+            memcpy(old_rec, o->shadow.data() + i * 32, 32);
+            memcpy(old_rec + (lo - i * 32), before.data() + (lo - offset), hi - lo);
+            if (memcmp(old_rec + 12, o->shadow.data() + i * 32 + 12, 4) != 0 || memcmp(old_rec + 28, o->shadow.data() + i * 32 + 28, 4) != 0)
+                return 0;  // topology changed
+        }
+        for (size_t i = a; i < b; i++) {
+            float box[8];
+            memcpy(box, o->shadow.data() + i * 32, 32);
+            if (i == 0) { memcpy(ctx->root_box, box, 12); memcpy(ctx->root_box + 3, box + 4, 12); }
+            if (i >= ctx->node_slot.size()) return 0;
+            const int32_t ns = ctx->node_slot[i];
+            if (ns < 0) continue;  // the root, a mesh's root, or a node the traversal cannot reach
+            const size_t blk = (size_t)(ns >> 3) * 64, l = (size_t)(ns & 7);
+            float* h = ctx->h_blocks.data() + blk;
+            const int plane_of[6] = {0, 1, 2, 4, 5, 6};
+            for (int k = 0; k < 6; k++) {
+                h[k * 8 + l] = box[plane_of[k]];
+                HIP_TRY(ctx, hipMemcpyAsync((float*)ctx->d_blocks + blk + k * 8 + l, h + k * 8 + l, 4, hipMemcpyHostToDevice, ctx->stream));
+            }
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return 1;
+    }
+    return 0;  // object ids and anything else: rebuild
+}
+
 // Walks the node buffer exactly as the kernel will and checks every index it
 // can reach, and computes the deepest the traversal stack can get.
 static int validate_scene(ptk_ctx* ctx) {
@@ -475,11 +588,13 @@ static int validate_scene(ptk_ctx* ctx) {
 
     // Compile the inner nodes for the traversal kernel (layout in PtkWavefront): block b holds the boxes
     // and entries of one inner node's children; blocks are numbered parent first, depth first.
-    std::vector<float> blocks;
+    std::vector<float>& blocks = ctx->h_blocks;
+    blocks.clear();
     std::vector<int32_t> sockets;
+    ctx->node_slot.assign((size_t)n_nodes, -1);
     if (wf_ok) {
         struct Compiler {
-            const NodeView& nv; std::vector<float>& blocks; std::vector<int32_t>& sockets;
+            const NodeView& nv; std::vector<float>& blocks; std::vector<int32_t>& sockets; std::vector<int32_t>& node_slot;
             uint32_t compile(int i, bool in_mesh) {
                 const int id = nv.node_id(i);
                 const int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
@@ -502,10 +617,11 @@ static int validate_scene(ptk_ctx* ctx) {
                     blk[0 + l] = box[0]; blk[8 + l] = box[1]; blk[16 + l] = box[2];
                     blk[24 + l] = box[4]; blk[32 + l] = box[5]; blk[40 + l] = box[6];
                     memcpy(blk + 48 + l, &e, 4);
+                    node_slot[(size_t)idx + l] = (int32_t)(b * 8 + l);
                 }
                 return (uint32_t)b | ((uint32_t)size << 24);
             }
-        } compiler{nv, blocks, sockets};
+        } compiler{nv, blocks, sockets, ctx->node_slot};
         ctx->root_entry = compiler.compile(0, false);
         memcpy(ctx->root_box, nv.p, 12);
         memcpy(ctx->root_box + 3, nv.p + 16, 12);
@@ -523,7 +639,10 @@ static int validate_scene(ptk_ctx* ctx) {
 
     // leaf records: what a leaf tests for object-id slot i, by value, so the traversal kernel reads a
     // leaf's primitives from consecutive addresses without going through the id table first
-    std::vector<float> leaf_records((size_t)std::max(n_ids, 1) * 12, 0.0f);
+    std::vector<float>& leaf_records = ctx->h_leaf_records;
+    leaf_records.assign((size_t)std::max(n_ids, 1) * 12, 0.0f);
+    ctx->tri_slot.assign((size_t)n_tri, -1);
+    ctx->sph_slot.assign((size_t)n_sph, -1);
     for (int i = 0; i < n_ids; i++) {
         const int oid = idp[i];
         const int type = sext(oid, 24, 8), oi = sext(oid, 0, 24);
@@ -532,29 +651,22 @@ static int validate_scene(ptk_ctx* ctx) {
             const uint8_t* t = tri->shadow.data() + (size_t)oi * 80;
             memcpy(r + 0, t + 0, 12); memcpy(r + 4, t + 16, 12); memcpy(r + 8, t + 32, 12);
             memcpy(r + 3, &oid, 4);
+            ctx->tri_slot[oi] = ctx->tri_slot[oi] == -1 ? i : -2;  // -2: listed more than once
         } else if (type == 1 && oi >= 0 && oi < n_sph) {
             const uint8_t* sp = sph->shadow.data() + (size_t)oi * 32;
             memcpy(r + 0, sp, 12); memcpy(r + 4, sp + 12, 4);
             memcpy(r + 3, &oid, 4);
+            ctx->sph_slot[oi] = ctx->sph_slot[oi] == -1 ? i : -2;
         }
     }
     if (ctx->d_leaf_records) { (void)hipFree(ctx->d_leaf_records); ctx->d_leaf_records = nullptr; }
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_leaf_records, leaf_records.size() * 4));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_leaf_records, leaf_records.data(), leaf_records.size() * 4, hipMemcpyHostToDevice, ctx->stream));
 
-    // planes with a non-zero normal, in index order
-    std::vector<int> live;
-    for (int i = 0; i < n_pln; i++) {
-        float nrm[3];
-        memcpy(nrm, pln->shadow.data() + (size_t)i * 32, 12);
-        if (!(nrm[0] == 0.0f && nrm[1] == 0.0f && nrm[2] == 0.0f)) live.push_back(i);
-    }
-    if (ctx->d_live_planes) { (void)hipFree(ctx->d_live_planes); ctx->d_live_planes = nullptr; }
-    ctx->n_live_planes = (int)live.size();
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_live_planes, std::max<size_t>(4, live.size() * 4)));
-    if (!live.empty()) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_live_planes, live.data(), live.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    { int r = refresh_live_planes(ctx, pln); if (r != PTK_OK) return r; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->dirty = false;
+    ctx->full_validations++;
     return PTK_OK;
 }
 
@@ -800,6 +912,13 @@ int ptk_debug_wf_stats(ptk_ctx* ctx, unsigned long long* out16) {
     return PTK_OK;
 }
 #endif
+
+int ptk_update_stats(ptk_ctx* ctx, long long* full_validations, long long* patched_updates) {
+    if (!ctx || !full_validations || !patched_updates) return PTK_E_INVALID;
+    *full_validations = ctx->full_validations;
+    *patched_updates = ctx->patched_updates;
+    return PTK_OK;
+}
 
 int ptk_set_renderer(ptk_ctx* ctx, int renderer) {
     if (!ctx) return PTK_E_INVALID;

@@ -29,7 +29,7 @@ EXPORTS = [
     "ptk_buffer_read", "ptk_image_create", "ptk_image_read", "ptk_image_update", "ptk_texture_create",
     "ptk_dispatch", "ptk_sync", "ptk_free", "ptk_bvh_build", "ptk_bvh_sizes", "ptk_bvh_read",
     "ptk_trace_enable", "ptk_trace_read", "ptk_last_dispatch_ms", "ptk_dispatch_history_ms", "ptk_image_copy_device",
-    "ptk_set_renderer", "ptk_dispatch_traverse_ms",
+    "ptk_set_renderer", "ptk_dispatch_traverse_ms", "ptk_update_stats",
 ]
 
 PTK_RENDERER_AUTO, PTK_RENDERER_SINGLE_KERNEL, PTK_RENDERER_WAVEFRONT = 0, 1, 2
@@ -94,6 +94,8 @@ def load_library() -> C.CDLL:
     lib.ptk_dispatch_history_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     lib.ptk_image_copy_device.restype = C.c_int
     lib.ptk_image_copy_device.argtypes = [vp, u64, vp, C.c_size_t, C.c_int]
+    lib.ptk_update_stats.restype = C.c_int
+    lib.ptk_update_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     lib.ptk_set_renderer.restype = C.c_int
     lib.ptk_set_renderer.argtypes = [vp, C.c_int]
     lib.ptk_dispatch_traverse_ms.restype = C.c_int
@@ -246,6 +248,12 @@ class PtkRenderingDevice:
         arr = (C.c_float * n)()
         self._check(self.lib.ptk_dispatch_history_ms(self.ctx, arr, n), "ptk_dispatch_history_ms")
         return [float(x) for x in arr]
+
+    def update_stats(self):
+        """(full validations of the bound scene, buffer updates absorbed by patching derived data)."""
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        self._check(self.lib.ptk_update_stats(self.ctx, C.byref(a), C.byref(b)), "ptk_update_stats")
+        return int(a.value), int(b.value)
 
     def set_renderer(self, renderer: int):
         """PTK_RENDERER_AUTO / _SINGLE_KERNEL / _WAVEFRONT: the schedule used for the next dispatches."""

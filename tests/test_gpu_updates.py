@@ -1,0 +1,108 @@
+"""GPU parity of the incremental edit path (pt_renderer.gd:664-788): single records and node boxes are
+rewritten with buffer_update between samples.  After every edit both renderers must still match the CPU
+oracle fed with the same bytes, and edits that keep the tree's topology must be absorbed without a full
+re-validation of the scene."""
+import copy
+import struct
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from test_gpu_parity import _compare_image, rd, rd_wf  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+def _render_all(pta, devs, packed, scene, win, k, cpu):
+    wd = pta.work_dispatcher
+    t = wd.sample_time(k)
+    win.frame = k
+    ob.render(packed, wd.push_constant_bytes(scene.camera, win, t), cpu, win.work_group_width, win.work_group_height)
+    for name, dev, disp in devs:
+        disp.create_compute_list(win, scene.camera, t, sync=True)
+        _compare_image(f"{name}[{k}]", dev.texture_get_data(disp.image_buffer), cpu)
+
+
+def _edit(packed, field, offset, data):
+    b = bytearray(getattr(packed, field))
+    b[offset:offset + len(data)] = data
+    setattr(packed, field, bytes(b))
+
+
+@pytest.mark.parametrize("scene_name", ["benchmark_random_scene", "dragon_test"])
+def test_edits_between_samples(pta, rd, rd_wf, golden_dir, scene_name):
+    wd = pta.work_dispatcher
+    scene = pta.scenes.load_fixture_scene(scene_name, golden_dir)
+    packed = copy.copy(wd.pack_scene(scene, ob.OracleBvhBuilder(), 8))
+    w, h = 320, 184
+    devs = []
+    for name, dev in (("one-kernel", rd), ("wavefront", rd_wf)):
+        d = wd.PTWorkDispatcher(dev)
+        d.create_buffers(w, h, packed=packed)
+        d.load_shader()
+        devs.append((name, dev, d))
+    win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=5, max_refraction_bounces=4)
+    cpu = np.zeros((h, w, 4), np.float32)
+    rd.set_renderer(pta.rendering_device.PTK_RENDERER_SINGLE_KERNEL)
+    try:
+        _render_all(pta, devs, packed, scene, win, 0, cpu)
+        base_stats = [dev.update_stats() for _, dev, _ in devs]
+
+        def apply(field, attr, offset, data):
+            _edit(packed, field, offset, data)
+            for _, dev, d in devs:
+                dev.buffer_update(getattr(d, attr), offset, len(data), data)
+
+        # 1. a material changes colour (nothing derived depends on material contents)
+        apply("materials", "material_buffer", 2 * 64, struct.pack("<3f", 0.9, 0.2, 0.1))
+        # 2. primitives shrink / move inside their old boxes
+        n_sph = len(packed.spheres) // 32
+        for i in range(0, min(n_sph, 40), 3):
+            c = struct.unpack_from("<4f", packed.spheres, i * 32)
+            if c[3] > 0:
+                apply("spheres", "sphere_buffer", i * 32, struct.pack("<4f", c[0], c[1], c[2], c[3] * 0.5))
+        n_tri = len(packed.triangles) // 80
+        for i in range(0, min(n_tri, 400), 7):
+            a = np.frombuffer(packed.triangles, np.float32, 12, i * 80).copy()
+            centre = (a[0:3] + a[4:7] + a[8:11]) / np.float32(3)
+            for v in (0, 4, 8):  # pull the corners a quarter of the way towards the centre
+                a[v:v + 3] = a[v:v + 3] * np.float32(0.75) + centre * np.float32(0.25)
+            apply("triangles", "triangle_buffer", i * 80, a.tobytes())
+        _render_all(pta, devs, packed, scene, win, 1, cpu)
+        # 3. node boxes grow a little (a refit after a move); ids and transform indices stay
+        n_nodes = len(packed.bvh) // 32
+        for i in range(1, min(n_nodes, 200), 5):
+            rec = np.frombuffer(packed.bvh, np.float32, 8, i * 32).copy()
+            words = np.frombuffer(packed.bvh, np.int32, 8, i * 32)
+            if words[3] == 0 and words[7] == 0:
+                continue  # padding record
+            rec[0:3] -= np.float32(0.125)
+            rec[4:7] += np.float32(0.125)
+            apply("bvh", "bvh_buffer", i * 32, rec[0:3].tobytes())         # min corner only
+            apply("bvh", "bvh_buffer", i * 32 + 16, rec[4:7].tobytes())    # max corner only
+        # 4. a plane is switched off (zero normal) if the scene has one
+        if any(struct.unpack_from("<3f", packed.planes, 0)):
+            apply("planes", "plane_buffer", 0, struct.pack("<3f", 0.0, 0.0, 0.0))
+        _render_all(pta, devs, packed, scene, win, 2, cpu)
+        for (_, dev, _), (full0, patched0) in zip(devs, base_stats):
+            full, patched = dev.update_stats()
+            assert full == full0, "topology-preserving edits must not trigger a full re-validation"
+            assert patched > patched0
+        # 5. the object-id table is rewritten (same contents): this one does rebuild
+        apply("object_ids", "object_id_buffer", 0, packed.object_ids[:8])
+        _render_all(pta, devs, packed, scene, win, 3, cpu)
+        for (_, dev, _), (full0, _) in zip(devs, base_stats):
+            assert dev.update_stats()[0] == full0 + 1
+        # 6. an edit that breaks the scene is reported at the next dispatch, not executed
+        bad = struct.pack("<i", 10 ** 6)
+        for _, dev, d in devs:
+            dev.buffer_update(d.sphere_buffer, 16, 4, bad)  # material index of sphere 0
+            with pytest.raises(pta.PtkError):
+                d.create_compute_list(win, scene.camera, 0.0, sync=True)
+            dev.buffer_update(d.sphere_buffer, 16, 4, packed.spheres[16:20])
+            d.create_compute_list(win, scene.camera, 0.0, sync=True)
+    finally:
+        rd.set_renderer(pta.rendering_device.PTK_RENDERER_AUTO)
+        for _, _, d in devs:
+            d.free_rids()
