@@ -126,6 +126,8 @@ def main():
         disp.create_compute_list(win, scene.camera, wd.sample_time(sample_index(k)), sync=True)
         counters += rd.trace_read_counters(disp.image_buffer).reshape(-1, pta.rendering_device.PTK_NCOUNTERS).sum(0)
     rd.trace_enable(0)
+    # AUTO would spend its first four dispatches timing both schedules; the bench pins the pipeline it reports on
+    rd.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
     cnt = dict(zip(pta.rendering_device.COUNTER_NAMES, counters.tolist()))
     rays_local = cnt["rays"]
 

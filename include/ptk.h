@@ -144,9 +144,11 @@ int ptk_dispatch_history_ms(ptk_ctx* ctx, float* ms, int n);
  * schedule.  The library renders a dispatch either with one kernel that runs a pixel's whole bounce
  * loop (ray_tracer.comp:1553-1635 as written) or as a wavefront pipeline (one traversal launch and one
  * shading launch per bounce over ray queues in device memory).  Both produce the same image bit for
- * bit.  AUTO takes the wavefront pipeline whenever it covers the dispatch: plain render mode, BVH
- * flag set, no tracing, no early-t variant.  WAVEFRONT makes ptk_dispatch fail with
- * PTK_E_UNSUPPORTED where AUTO would fall back. */
+ * bit.  The pipeline covers plain render mode with the BVH flag set, no tracing, no early-t variant and
+ * at most 32 bounces.  Where both apply, AUTO times each schedule on the first dispatches of a workload
+ * (scene contents, group counts, depth limits) and keeps the faster one: the pipeline wins on heavy
+ * scenes, the single kernel on light ones where per-bounce launches dominate.  WAVEFRONT makes
+ * ptk_dispatch fail with PTK_E_UNSUPPORTED where the pipeline does not apply. */
 enum { PTK_RENDERER_AUTO = 0, PTK_RENDERER_SINGLE_KERNEL = 1, PTK_RENDERER_WAVEFRONT = 2 };
 int ptk_set_renderer(ptk_ctx* ctx, int renderer);
 /* Durations (ms) of the traversal-kernel launches of the dispatch `back` calls ago (0 = the last

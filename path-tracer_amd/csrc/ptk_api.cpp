@@ -78,6 +78,15 @@ struct ptk_ctx {
     std::vector<int32_t> node_slot;  // node index -> block * 8 + child slot holding its box, -1 if none
     std::vector<int32_t> tri_slot, sph_slot;  // primitive index -> object-id slot holding its record, -1 if none
     long long full_validations = 0, patched_updates = 0;
+    // AUTO renderer choice: both schedules give the same image, so the first dispatches of a workload
+    // are used to time each of them (twice) and the faster one is kept until the workload changes
+    struct AutoChoice {
+        unsigned long long key = 0;       // what was timed: scene version, groups, depth limits, image
+        float best_ms[2] = {-1.0f, -1.0f};  // [0] one-kernel renderer, [1] wavefront pipeline
+        int samples[2] = {0, 0};
+        long long probe_dispatch[2] = {-1, -1};  // dispatch number of a timing still in flight
+    } auto_choice;
+    unsigned long long scene_version = 0;
     float4* d_leaf_records = nullptr;  // per object-id slot: the primitive by value (48 bytes)
     void* d_wf = nullptr;          // queues + path state, one allocation
     size_t wf_slots = 0;
@@ -267,7 +276,7 @@ int ptk_buffer_update(ptk_ctx* ctx, uint64_t buffer, size_t offset, const void* 
     const int patched = patch_derived(ctx, o, offset, nbytes, before);
     if (patched < 0) { ctx->dirty = true; return patched; }
     if (patched == 0) ctx->dirty = true;
-    else ctx->patched_updates++;
+    else { ctx->patched_updates++; ctx->scene_version++; }
     return PTK_OK;
 }
 
@@ -667,6 +676,7 @@ static int validate_scene(ptk_ctx* ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->dirty = false;
     ctx->full_validations++;
+    ctx->scene_version++;
     return PTK_OK;
 }
 
@@ -818,7 +828,35 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
                              !trace && !ctx->early_t_break && P.push.max_default_depth > 0 && n_iter <= PTK_WF_MAX_ITER;
     if (ctx->renderer == PTK_RENDERER_WAVEFRONT && !wf_eligible)
         return fail(ctx, PTK_E_UNSUPPORTED, "the wavefront renderer does not cover this dispatch (render mode, flags, tracing, early-t, depth > %d or nested mesh sockets)", PTK_WF_MAX_ITER);
-    const bool use_wf = wf_eligible && ctx->renderer != PTK_RENDERER_SINGLE_KERNEL;
+    bool use_wf = wf_eligible && ctx->renderer != PTK_RENDERER_SINGLE_KERNEL;
+    int probing = -1;  // this dispatch times renderer `probing` for the AUTO choice
+    if (wf_eligible && ctx->renderer == PTK_RENDERER_AUTO) {
+        ptk_ctx::AutoChoice& ac = ctx->auto_choice;
+        unsigned long long key = ctx->scene_version * 0x9E3779B97F4A7C15ull;
+        for (unsigned long long v : {(unsigned long long)groups_x, (unsigned long long)groups_y, (unsigned long long)n_iter,
+                                     (unsigned long long)P.push.max_default_depth, (unsigned long long)ctx->image,
+                                     (unsigned long long)ctx->refraction_mode, (unsigned long long)ctx->use_emission})
+            key = (key ^ v) * 0x100000001B3ull;
+        if (key != ac.key) ac = ptk_ctx::AutoChoice(), ac.key = key;
+        for (int k = 0; k < 2; k++) {  // collect timings that have completed (never blocks)
+            if (ac.probe_dispatch[k] < 0) continue;
+            if (ctx->dispatch_count - ac.probe_dispatch[k] >= ptk_ctx::kTimingRing) { ac.probe_dispatch[k] = -1; continue; }
+            const int ps = (int)(ac.probe_dispatch[k] % ptk_ctx::kTimingRing);
+            if (hipEventQuery(ctx->ev1[ps]) != hipSuccess) continue;
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ctx->ev0[ps], ctx->ev1[ps]) == hipSuccess) {
+                ac.best_ms[k] = ac.samples[k] == 0 ? ms : std::min(ac.best_ms[k], ms);
+                ac.samples[k]++;
+            }
+            ac.probe_dispatch[k] = -1;
+        }
+        const int kProbes = 2;
+        if (ac.samples[0] < kProbes && ac.probe_dispatch[0] < 0) probing = 0;
+        else if (ac.samples[1] < kProbes && ac.probe_dispatch[1] < 0) probing = 1;
+        if (probing >= 0) { use_wf = probing == 1; ac.probe_dispatch[probing] = ctx->dispatch_count; }
+        else if (ac.samples[0] >= kProbes && ac.samples[1] >= kProbes) use_wf = ac.best_ms[1] <= ac.best_ms[0];
+        // (timings still in flight: the wavefront pipeline meanwhile)
+    }
 
     if (!use_wf) {
         ctx->wf_iters[slot] = 0;

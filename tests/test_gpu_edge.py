@@ -87,13 +87,42 @@ def test_wavefront_hands_over_outside_its_range(pta, rd, golden_dir):
             ob.render(packed, push, cpu, w // 8, h // 8)
             dev.set_renderer(pta.rendering_device.PTK_RENDERER_AUTO)
             d.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
-            used_wavefront = len(dev.dispatch_traverse_ms(0)) > 0
-            assert used_wavefront == (depth == 8)
+            if depth != 8:
+                assert dev.dispatch_traverse_ms(0) == [], "outside its range the pipeline must not run"
             _compare_image(f"depth{depth}", dev.texture_get_data(d.image_buffer), cpu)
             if depth != 8:
                 dev.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
                 with pytest.raises(pta.PtkError):
                     d.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
+        d.free_rids()
+    finally:
+        dev.close()
+
+
+def test_auto_renderer_settles_on_the_faster_schedule(pta, golden_dir):
+    """AUTO times both schedules on the first dispatches and keeps one; every dispatch on the way, whichever
+    schedule rendered it, gives the oracle's image.  A light scene ends on the one-kernel renderer."""
+    wd = pta.work_dispatcher
+    scene = pta.scenes.load_fixture_scene("fake_cornell_box", golden_dir)
+    packed = wd.pack_scene(scene, ob.OracleBvhBuilder(), 8)
+    w, h = 256, 144
+    dev = pta.PtkRenderingDevice(0)
+    try:
+        d = wd.PTWorkDispatcher(dev)
+        d.create_buffers(w, h, packed=packed)
+        d.load_shader()
+        cpu = np.zeros((h, w, 4), np.float32)
+        used = []
+        for k in range(10):
+            win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=6, max_refraction_bounces=4)
+            win.frame = k
+            t = wd.sample_time(k)
+            ob.render(packed, wd.push_constant_bytes(scene.camera, win, t), cpu, w // 8, h // 8)
+            d.create_compute_list(win, scene.camera, t, sync=True)
+            used.append(len(dev.dispatch_traverse_ms(0)) > 0)
+            _compare_image(f"auto[{k}]", dev.texture_get_data(d.image_buffer), cpu)
+        assert True in used[:4] and False in used[:4], "both schedules are tried first"
+        assert len(set(used[6:])) == 1, "then one of them is kept"
         d.free_rids()
     finally:
         dev.close()

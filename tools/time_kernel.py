@@ -7,7 +7,12 @@ pta = importlib.import_module("path-tracer_amd")
 wd = pta.work_dispatcher
 w, h = (3840, 2160) if os.environ.get("PTK_4K") else (1920, 1080)
 which = sys.argv[1] if len(sys.argv) > 1 else "atrium"
-scene = pta.scenes.atrium_scene(262144, seed=7) if which == "atrium" else pta.scenes.random_spheres_scene(100, 3)
+if which == "atrium":
+    scene = pta.scenes.atrium_scene(262144, seed=7)
+elif which == "spheres":
+    scene = pta.scenes.random_spheres_scene(100, 3)
+else:  # a fixture scene by name, e.g. benchmark_random_scene, dragon_test, fake_cornell_box
+    scene = pta.scenes.load_fixture_scene(which, os.path.join(ROOT, "tests", "golden"))
 rd = pta.PtkRenderingDevice(0)
 rd.set_renderer(int(os.environ.get("PTK_RENDERER", "0")))
 disp = wd.PTWorkDispatcher(rd)
