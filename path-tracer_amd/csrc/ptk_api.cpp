@@ -793,7 +793,8 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         P.spill = ctx->d_spill;
         P.spill_t = ctx->d_spill_t;
     }
-    size_t lds_bytes = (size_t)P.lds_cap * 64 * 4 * (ctx->early_t_break ? 2 : 1);
+    // the block traversal (untraced, no early-t) writes rejected children to one spare row past the window
+    size_t lds_bytes = ctx->early_t_break ? (size_t)P.lds_cap * 64 * 4 * 2 : (size_t)(P.lds_cap + 1) * 64 * 4;
 
     const int trace = ctx->trace_flags != 0;
     if (trace) {
@@ -814,6 +815,18 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         ctx->trace_pixels = pixels;
         P.trace_primary = (ctx->trace_flags & PTK_TRACE_PRIMARY_ID) ? ctx->d_trace_primary : nullptr;
         P.trace_counters = (ctx->trace_flags & PTK_TRACE_COUNTERS) ? ctx->d_trace_counters : nullptr;
+    }
+
+    // the compiled node blocks and leaf records: read by the wavefront pipeline and by the untraced
+    // one-kernel renderer (null: that renderer walks the bound node buffer itself)
+    if (ctx->wf_ok && !trace && !ctx->early_t_break) {
+        P.wf.blocks = ctx->d_blocks;
+        P.wf.sockets = ctx->d_sockets;
+        P.wf.root_min_x = ctx->root_box[0]; P.wf.root_min_y = ctx->root_box[1]; P.wf.root_min_z = ctx->root_box[2];
+        P.wf.root_max_x = ctx->root_box[3]; P.wf.root_max_y = ctx->root_box[4]; P.wf.root_max_z = ctx->root_box[5];
+        P.wf.root_entry = ctx->root_entry;
+        P.wf.n_blocks = ctx->n_blocks; P.wf.n_sockets = ctx->n_sockets; P.wf.n_records = ctx->n_records;
+        P.wf.leaf_records = ctx->d_leaf_records;
     }
 
     const int slot = (int)(ctx->dispatch_count % ptk_ctx::kTimingRing);
@@ -891,13 +904,6 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         P.wf.inside = (int*)base;
         P.wf.n_slots = (uint32_t)n_slots;
         P.wf.tiles_x = groups_x;
-        P.wf.blocks = ctx->d_blocks;
-        P.wf.sockets = ctx->d_sockets;
-        memcpy(P.wf.root_min, ctx->root_box, 12);
-        memcpy(P.wf.root_max, ctx->root_box + 3, 12);
-        P.wf.root_entry = ctx->root_entry;
-        P.wf.n_blocks = ctx->n_blocks; P.wf.n_sockets = ctx->n_sockets; P.wf.n_records = ctx->n_records;
-        P.wf.leaf_records = ctx->d_leaf_records;
     }
     // persistent traversal waves: as many as fit on the device at once
     const size_t wf_lds = (size_t)(P.lds_cap + 1) * 64 * 4;  // one spare row for rejected children

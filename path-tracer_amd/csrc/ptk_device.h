@@ -59,7 +59,7 @@ struct PtkWavefront {
     // 0x7F000000 | socket index for a mesh socket met at world level.
     const float4* blocks;
     const int2* sockets;     // per world-level mesh socket: {entry of the mesh's root, transform index}
-    float root_min[3], root_max[3];
+    float root_min_x, root_min_y, root_min_z, root_max_x, root_max_y, root_max_z;  // box of the root node
     uint32_t root_entry;
     uint32_t n_blocks, n_sockets, n_records;  // array lengths (checked builds)
     const float4* leaf_records;  // 3 float4 per object-id slot: the primitive a leaf tests, by value

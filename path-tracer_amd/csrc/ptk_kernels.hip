@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64) void ptk_render_kernel(const PtkParams P) {
         Hit h;
         if (!use_bvh) h = check_ray_hit_all<TRACE>(P, nr, cnt);
         else if (EARLY_T) h = check_ray_hit_bvh<TRACE, EARLY_T>(P, L, nr, S, ST, cnt);
+        else if (!TRACE && P.wf.blocks != nullptr && !show_bvh_view) h = check_ray_hit_blocks(P, nr, S);  // no counters kept
         else h = check_ray_hit_bvh2<TRACE>(P, L, nr, S, cnt);
         if (first) { primary = h.hit ? h.object_id : -1; first = false; }
         if (!h.hit) {

@@ -547,6 +547,233 @@ PTK_DEV Hit check_ray_hit_bvh2(const PtkParams& P, Lane& L, Ray& ray, const Stac
     return h;
 }
 
+// ---- traversal over compiled node blocks (PtkWavefront::blocks, ::sockets, ::leaf_records) ---------
+// The same search as check_ray_hit_bvh2 -- per lane the same order of box and object tests -- reading
+// the structures the host derives from the bound buffers: an inner node's eight child slots come as one
+// 256-byte block of planes, a leaf's primitives by value from consecutive records.  The state of one
+// ray's search between steps is a Trav; the callers (the wavefront traversal kernel and the one-kernel
+// renderer) own the loop that votes between inner and leaf rounds.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct Trav {
+    f3 o, d;        // the ray; mesh-local while in a mesh
+    float start, end;
+    f3 inv;         // 1 / d
+    Hit h;
+    uint32_t cur;   // next node: entry word or ENTRY_NONE
+    int sp;
+    int sub_base;   // stack level at which the mesh in progress was entered
+    int cur_xf;     // its transform index, -1 at world level
+    f3 w_o, w_d;    // the world ray while in a mesh
+    float w_start, dir_len;
+};
+
+PTK_DEV bool trav_is_leaf(const Trav& T) { return T.cur != ENTRY_NONE && (int)T.cur <= 0; }
+PTK_DEV bool trav_is_inner(const Trav& T) { return T.cur != ENTRY_NONE && (int)T.cur > 0; }
+
+// planes first, outside the BVH (:1204; only records with a non-zero normal can hit), then the root box
+PTK_DEV void trav_begin(const PtkParams& P, Trav& T, const Ray& world_ray) {
+    const PtkWavefront& W = P.wf;
+    Ray r = world_ray;
+    T.h.hit = 0; T.h.object_id = 0; T.h.transform_index = -1; T.h.u = 0.0f; T.h.v = 0.0f;
+    for (int i = 0; i < P.n_live_planes; ++i) hit_plane(P, r, T.h, P.live_planes[i], -1);
+    T.o = r.o; T.d = r.d; T.start = r.start; T.end = r.end;
+    T.inv = mk3(1.0f / T.d.x, 1.0f / T.d.y, 1.0f / T.d.z);
+    const int neg = (T.inv.x < 0.0f ? 1 : 0) | (T.inv.y < 0.0f ? 2 : 0) | (T.inv.z < 0.0f ? 4 : 0);
+    const float4 rmin = make_float4(W.root_min_x, W.root_min_y, W.root_min_z, 0.0f);
+    const float4 rmax = make_float4(W.root_max_x, W.root_max_y, W.root_max_z, 0.0f);
+    const float root_hit = hit_aabb_bl(rmin, rmax, T.o, T.inv, neg, T.start, T.end);
+    T.cur = in_range(root_hit, T.start, T.end) ? W.root_entry : ENTRY_NONE;
+    T.sp = 0;
+    T.sub_base = 0;
+    T.cur_xf = -1;
+    T.dir_len = 1.0f;
+}
+
+// One inner step of a lane whose T.cur is an inner entry: enter a mesh socket, or slab-test the node's
+// children and push the accepted ones nearest-on-top (:1144-1180).  Returns true if the lane now needs its
+// next node from the stack (no child accepted).  The stack's LDS window must have one spare row past
+// S.lds_cap (rejected children are written there).
+PTK_DEV bool trav_inner(const PtkParams& P, const Stack& S, Trav& T) {
+    const PtkWavefront& W = P.wf;
+    uint32_t cur = T.cur;
+    if ((cur & 0xFF000000u) == SOCKET_MARK) {
+        // world level: enter the mesh (:1286-1313); its root is the next node
+        const int2 sock = W.sockets[cur & 0x00FFFFFFu];
+        const int xf = sock.y;
+        const m44 M = load_xform(P, xf);
+        T.w_o = T.o; T.w_d = T.d; T.w_start = T.start;
+        const f3 unnorm = mul_mv(M, T.d, 0.0f);
+        T.dir_len = length3(unnorm);
+        const f3 no = mul_mv(M, T.o, 1.0f);
+        T.d = div3(unnorm, T.dir_len);
+        T.o = no;
+        T.end = T.end * T.dir_len;
+        T.start = T.start * T.dir_len;
+        T.inv = mk3(1.0f / T.d.x, 1.0f / T.d.y, 1.0f / T.d.z);
+        T.sub_base = T.sp;
+        T.cur_xf = xf;
+        T.cur = (uint32_t)sock.x;
+        return false;
+    }
+    int* const lds_lane = S.lds + S.lane;
+    const int sp = T.sp;
+    const int node_size = (int)(cur >> 24);
+    // the node's block: eight child slots as planes (minx[8] .. maxz[8], entry[8]), all fetched before
+    // any is used; slots past node_size hold zeros and are ignored
+    const float4* __restrict__ cb = W.blocks + (size_t)(cur & 0x00FFFFFFu) * 16;
+    float4 q[14];
+#pragma unroll
+    for (int k = 0; k < 14; k++) q[k] = cb[k];
+    __builtin_amdgcn_sched_barrier(0);
+    const f3 o = T.o, inv = T.inv;
+    const float rstart = T.start, rend = T.end;
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    // a NaN in the ray's own range (singular mesh transform) fails in_range for every box
+    const bool range_ok = rstart == rstart && rend == rend;
+    // key = bits of the entry distance t (t >= +0, so unsigned integer order is float order); rejected
+    // children get the bits of +inf, which no accepted t reaches
+    uint32_t key[PTK_MAX_WIDTH];
+    uint32_t ent[PTK_MAX_WIDTH];
+    int added = 0;
+#pragma unroll
+    for (int c = 0; c < PTK_MAX_WIDTH / 2; c++) {
+        // hit_AABB (:670-689) for children 2c and 2c+1 side by side in packed fp32: per axis
+        // t0 = (min - o) * inv, t1 = (max - o) * inv, the arithmetic swap when inv < 0, then start = max,
+        // end = min.  start and end are never NaN and only move inwards, so testing end <= start once
+        // after the last axis equals the shader's three early returns, and a box that passes has its t
+        // inside [ray.start, ray.end] already.
+        const int h4 = c >> 1;          // which float4 of the plane
+        const bool hi2 = (c & 1) != 0;  // .zw or .xy
+#define PTK_PAIR(v) (hi2 ? v2f{(v).z, (v).w} : v2f{(v).x, (v).y})
+        const v2f lox = PTK_PAIR(q[0 + h4]), loy = PTK_PAIR(q[2 + h4]), loz = PTK_PAIR(q[4 + h4]);
+        const v2f hix = PTK_PAIR(q[6 + h4]), hiy = PTK_PAIR(q[8 + h4]), hiz = PTK_PAIR(q[10 + h4]);
+        const v2f en = PTK_PAIR(q[12 + h4]);
+#undef PTK_PAIR
+        const v2f t0x = (lox - o.x) * inv.x, t1x = (hix - o.x) * inv.x;
+        const v2f t0y = (loy - o.y) * inv.y, t1y = (hiy - o.y) * inv.y;
+        const v2f t0z = (loz - o.z) * inv.z, t1z = (hiz - o.z) * inv.z;
+        const v2f swx = t0x + t1x, sbx = swx - t1x, scx = swx - sbx;
+        const v2f swy = t0y + t1y, sby = swy - t1y, scy = swy - sby;
+        const v2f swz = t0z + t1z, sbz = swz - t1z, scz = swz - sbz;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int l = 2 * c + e;
+            float start = rstart, end = rend;
+            start = __builtin_fmaxf(start, nx ? scx[e] : t0x[e]);
+            end = __builtin_fminf(end, nx ? sbx[e] : t1x[e]);
+            start = __builtin_fmaxf(start, ny ? scy[e] : t0y[e]);
+            end = __builtin_fminf(end, ny ? sby[e] : t1y[e]);
+            start = __builtin_fmaxf(start, nz ? scz[e] : t0z[e]);
+            end = __builtin_fminf(end, nz ? sbz[e] : t1z[e]);
+            const bool acc = (l < node_size) && (end > start) && range_ok;
+            key[l] = acc ? (fbits(start) & 0x7FFFFFFFu) : 0x7F800000u;
+            ent[l] = fbits(en[e]);
+            added += acc ? 1 : 0;
+        }
+    }
+    // rank = number of children the shader's selection loop (:1157-1178) would take earlier: smaller t, or
+    // equal t in a lower slot.  For j < l, u = 1 iff child l is strictly nearer than child j (sign bit of
+    // key[l] - key[j]; both keys < 2^31): rank[l] = l - sum_{j<l} u(j,l) + sum_{m>l} u(l,m).
+    int up[PTK_MAX_WIDTH], dn[PTK_MAX_WIDTH];
+#pragma unroll
+    for (int l = 0; l < PTK_MAX_WIDTH; l++) { up[l] = 0; dn[l] = 0; }
+#pragma unroll
+    for (int l = 1; l < PTK_MAX_WIDTH; l++) {
+#pragma unroll
+        for (int j = 0; j < l; j++) {
+            const int u = (int)((key[l] - key[j]) >> 31);
+            up[j] += u;
+            dn[l] += u;
+        }
+    }
+    // rank r goes to stack slot sp + added - 1 - r, so the nearest child lands in the free slot above the
+    // new top and is read back as `cur`; rejected children (rank >= added) are sent to the spare row.
+    cur = ENTRY_NONE;
+    const int top = sp + added - 1;
+    if (sp + PTK_MAX_WIDTH <= S.lds_cap) {
+#pragma unroll
+        for (int l = 0; l < PTK_MAX_WIDTH; l++) {
+            const int rank = l - dn[l] + up[l];
+            lds_lane[((key[l] != 0x7F800000u) ? top - rank : S.lds_cap) * 64] = (int)ent[l];
+        }
+        if (added > 0) cur = (uint32_t)lds_lane[top * 64];
+    } else {
+#pragma unroll
+        for (int l = 0; l < PTK_MAX_WIDTH; l++) {
+            const int rank = l - dn[l] + up[l];
+            if (key[l] != 0x7F800000u) {
+                if (rank == 0) cur = ent[l];
+                else st_write(S, top - rank, (int)ent[l]);
+            }
+        }
+    }
+    T.cur = cur;
+    T.sp = sp + ((added > 0) ? added - 1 : 0);
+    return added == 0;
+}
+
+// One leaf round for the whole wave: lanes with is_leaf test their leaf's objects in order (:1137-1142);
+// the loop runs to the largest leaf among them.  Leaf records: {A.xyz | centre.xyz, object id},
+// {B.xyz | radius, -}, {C.xyz, -}, stored in object-id-slot order.
+PTK_DEV void trav_leaf(const PtkParams& P, Trav& T, bool is_leaf) {
+    int node_size = 0, base = 0;
+    if (is_leaf) {
+        node_size = iabs(bfe_i((int)T.cur, 24, 8));
+        base = iabs(bfe_i((int)T.cur, 0, 24)) - 1;
+    }
+    const float4* __restrict__ rec = P.wf.leaf_records + (size_t)base * 3;
+    Ray r;
+    r.o = T.o; r.d = T.d; r.start = T.start; r.end = T.end;
+    for (int k = 0;; k++) {
+        const bool go = k < node_size;
+        if (__ballot(go) == 0ull) break;
+        if (go) {
+            const float4 r0 = rec[k * 3], r1 = rec[k * 3 + 1], r2 = rec[k * 3 + 2];
+            const int object_id = (int)fbits(r0.w);
+            const int type = bfe_i(object_id, 24, 8);
+            if (type == IS_TRIANGLE) hit_triangle_rec(r, T.h, object_id, T.cur_xf, ld3(r0), ld3(r1), ld3(r2));
+            else if (type == IS_SPHERE) hit_sphere_rec(r, T.h, object_id, T.cur_xf, ld3(r0), r1.x);
+        }
+    }
+    T.end = r.end;
+}
+
+// Next node of the lane: pop; an empty mesh sub-stack first maps the ray back to world space (:1309-1310).
+PTK_DEV void trav_pop(const Stack& S, Trav& T) {
+    T.cur = ENTRY_NONE;
+    if (T.cur_xf >= 0 && T.sp <= T.sub_base) {
+        const float local_end = T.end;
+        T.o = T.w_o; T.d = T.w_d; T.start = T.w_start;
+        T.end = local_end / T.dir_len;
+        T.inv = mk3(1.0f / T.d.x, 1.0f / T.d.y, 1.0f / T.d.z);
+        T.cur_xf = -1;
+    }
+    if (T.sp > 0) T.cur = (uint32_t)st_read(S, --T.sp);
+}
+
+// The whole search for the one-kernel renderer: every lane of the wave runs its own ray to the end.
+PTK_DEV Hit check_ray_hit_blocks(const PtkParams& P, Ray& ray, const Stack& S) {
+    Trav T;
+    T.w_o = ray.o; T.w_d = ray.d; T.w_start = ray.start;
+    trav_begin(P, T, ray);
+    for (;;) {
+        const bool is_leaf = trav_is_leaf(T), is_inner = trav_is_inner(T);
+        const unsigned long long mi = __ballot(is_inner), ml = __ballot(is_leaf);
+        if ((mi | ml) == 0ull) break;
+        bool pop = false;
+        if (PTK_VOTE_INNER(__popcll(mi), __popcll(ml))) {
+            if (is_inner) pop = trav_inner(P, S, T);
+        } else {
+            trav_leaf(P, T, is_leaf);
+            pop = is_leaf;
+        }
+        if (pop) trav_pop(S, T);
+    }
+    ray.end = T.end;
+    return T.h;
+}
+
 // Brute-force closest hit when USE_BVH is off, :1093-1101.
 template <bool TRACE>
 PTK_DEV Hit check_ray_hit_all(const PtkParams& P, Ray& ray, int* cnt) {
