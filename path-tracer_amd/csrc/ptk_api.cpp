@@ -937,26 +937,6 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     return PTK_OK;
 }
 
-#ifdef PTK_CHECKED
-// development build only: error words left by a traversal kernel compiled with index checks
-int ptk_debug_wf_check(ptk_ctx* ctx, unsigned* out4) {
-    if (!ctx || !ctx->d_wf) return PTK_E_STATE;
-    HIP_TRY(ctx, hipMemcpyAsync(out4, (uint8_t*)ctx->d_wf + 800, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PTK_OK;
-}
-#endif
-
-#ifdef PTK_ROUND_STATS
-// development build only: round counters of the traversal kernel (zeroed with the queue heads every dispatch)
-int ptk_debug_wf_stats(ptk_ctx* ctx, unsigned long long* out16) {
-    if (!ctx || !ctx->d_wf) return PTK_E_STATE;
-    HIP_TRY(ctx, hipMemcpyAsync(out16, (uint8_t*)ctx->d_wf + 512, 128, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PTK_OK;
-}
-#endif
-
 int ptk_update_stats(ptk_ctx* ctx, long long* full_validations, long long* patched_updates) {
     if (!ctx || !full_validations || !patched_updates) return PTK_E_INVALID;
     *full_validations = ctx->full_validations;
