@@ -558,6 +558,12 @@ static int validate_scene(ptk_ctx* ctx) {
             int id = nv.node_id(i);
             int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
             int x = nv.xform(i);
+            // The kernels tell a leaf from an inner node by the sign of the whole word.  That equals the
+            // shader's test on the 24-bit index (ray_tracer.comp:1137) for every id PTBVHTree writes
+            // (pt_bvh_tree.gd:910-959: inner = index ^ count << 24 with both positive, leaf = negative
+            // index ^ (count - 1) << 24); any other bit pattern is refused rather than misread.
+            if ((idx > 0 && id <= 0) || (idx < 0 && id >= 0))
+                return bad(PTK_E_UNSUPPORTED, "node %d: id 0x%08x is not in the encoding PTBVHTree writes", i, id);
             if (x >= n_xf) return bad(PTK_E_INVALID, "node %d: transform index %d out of range (%d)", i, x, n_xf);
             // (an all-zero root, the empty tree, has transform index 0 and child index 0: harmless)
             if (x >= 0 && idx < 0) return bad(PTK_E_INVALID, "node %d: a mesh socket (transform index %d) must have a child node", i, x);
@@ -776,6 +782,7 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     const int need = ctx->stack_need;
     P.lds_cap = std::min(need, kLdsWindow);
     const size_t lanes = (size_t)groups_x * groups_y * 64;
+    if (lanes > ((size_t)1 << 30)) return fail(ctx, PTK_E_UNSUPPORTED, "dispatch of %zu invocations; at most 2^30 per dispatch", lanes);
     P.spill_stride = lanes;
     const int spill_entries = need - P.lds_cap;
     if (spill_entries > 0) {

@@ -232,4 +232,15 @@ def test_error_paths(pta, rd):
     with pytest.raises(pta.PtkError):
         disp.create_compute_list(win, scene.camera, 0.0, sync=True)
     disp.free_rids()
+    # a leaf id whose whole word is positive (index -1, count byte +1): the shader would read it as a leaf of
+    # one, PTBVHTree never writes it; refused instead of being taken for an inner node
+    bad = bytearray(pta.work_dispatcher.pack_scene(scene, ob.OracleBvhBuilder(), 8).bvh)
+    struct.pack_into("<I", bad, 12, 0x01FFFFFF)
+    packed.bvh = bytes(bad)
+    disp = wd.PTWorkDispatcher(rd)
+    disp.create_buffers(64, 64, packed=packed)
+    disp.load_shader()
+    with pytest.raises(pta.PtkError):
+        disp.create_compute_list(win, scene.camera, 0.0, sync=True)
+    disp.free_rids()
     rd.configure()
