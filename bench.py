@@ -70,6 +70,18 @@ def measured_traffic(workload):
     return t.get("traverse_bytes_per_launch")
 
 
+def reference_runtime_note():
+    """The shader itself could only be timed by Godot 4.3 on a CPU Vulkan driver (lavapipe); say whether
+    this host has them (it never runs them: the oracle is the baseline that is timed)."""
+    import shutil
+
+    godot = shutil.which("godot") or shutil.which("godot4")
+    icd = any(os.path.isdir(d) and any("lvp" in f for f in os.listdir(d)) for d in ("/usr/share/vulkan/icd.d", "/etc/vulkan/icd.d"))
+    if godot and icd:
+        return "godot and lavapipe present but not driven by this harness; oracle timed"
+    return "lavapipe baseline unavailable (godot: %s, lavapipe icd: %s); oracle timed" % ("yes" if godot else "no", "yes" if icd else "no")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,6 +262,7 @@ def main():
             "kind": "port",
             "sample": "%d full 1920x1080 dispatches (1 spp each, depth 8) of the same scene and BVH; %.1f s of CPU work" % (n_cpu, cpu_s),
             "ms_per_step": cpu_s / n_cpu * 1e3,
+            "reference_runtime": reference_runtime_note(),
         }
     print(json.dumps(out))
     if world > 1:
