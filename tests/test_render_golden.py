@@ -1,5 +1,5 @@
 """Render fixtures: CRC-32 of the images the CPU oracle produced for the fixture scenes when
-tests/golden/render_crc.json was written (tools/make_render_golden.py).  The reference holds no render
+tests/golden/render_crc.json was written (tests/make_render_golden.py).  The reference holds no render
 vectors, so these do not pin the oracle to the reference; they pin it -- and the HIP renderers -- to a
 recorded state, across compilers and machines (all arithmetic is IEEE binary32 with fixed operation order)."""
 import importlib
