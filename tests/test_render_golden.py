@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 with open(os.path.join(ROOT, "tests", "golden", "render_crc.json")) as f:
     GOLDEN = json.load(f)
