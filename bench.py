@@ -238,7 +238,7 @@ def main():
         },
     }
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         # CPU baseline: the oracle (a restatement of ray_tracer.comp, not Godot/lavapipe, which do not
         # exist on this box) renders ONE full-frame dispatch of the same workload on the host cores.
         sys.path.insert(0, os.path.join(ROOT, "tests"))
