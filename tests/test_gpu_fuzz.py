@@ -1,0 +1,85 @@
+"""GPU parity on seeded random scenes: overlapping dielectric spheres with random priorities, metals,
+emitters, free triangles, planes, and meshes under rotated / non-uniformly scaled transforms, built with a
+random BVH type, at random depths and refraction-tracking modes.  Same bar as test_gpu_parity: primary
+ids, per-pixel counters and images bit-identical to the CPU oracle, for the one-kernel renderer and the
+wavefront pipeline."""
+import math
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import _run_case, rd, rd_wf  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+def _rotation(rng):
+    """A random rotation times a random non-uniform scale, as the nine row-major basis values."""
+    a, b, c = rng.uniform(0.0, 2.0 * math.pi, 3)
+    rx = np.array([[1, 0, 0], [0, math.cos(a), -math.sin(a)], [0, math.sin(a), math.cos(a)]])
+    ry = np.array([[math.cos(b), 0, math.sin(b)], [0, 1, 0], [-math.sin(b), 0, math.cos(b)]])
+    rz = np.array([[math.cos(c), -math.sin(c), 0], [math.sin(c), math.cos(c), 0], [0, 0, 1]])
+    scale = np.diag(rng.uniform(0.5, 1.8, 3))
+    return (rz @ ry @ rx @ scale).reshape(-1).tolist()
+
+
+def _random_description(seed):
+    rng = np.random.default_rng(seed)
+    mats = {}
+    for i in range(8):
+        kind = rng.integers(0, 4)
+        m = dict(albedo=rng.uniform(0.1, 1.0, 3).tolist(), roughness=0.0, metallic=0.0, opacity=1.0, reflectivity=1.0,
+                 IOR=1.0, dielectric_priority=0, is_emissive=0)
+        if kind == 1:
+            m["metallic"] = float(rng.uniform(0.2, 1.0))
+        elif kind == 2:  # dielectric, some of them "air" cut-outs (IOR 1)
+            m["opacity"] = float(rng.choice([0.0, 0.0, 0.4]))
+            m["IOR"] = float(rng.choice([1.0, 1.33, 1.5, 1.6, 2.4]))
+            m["reflectivity"] = float(rng.uniform(0.0, 1.0))
+            m["dielectric_priority"] = int(rng.integers(0, 4))
+        elif kind == 3 and i % 2 == 0:
+            m["albedo"] = rng.uniform(2.0, 15.0, 3).tolist()
+            m["is_emissive"] = 1
+        mats[f"m{i}"] = m
+    names = list(mats) + [None]
+
+    def pick():
+        return names[rng.integers(0, len(names))]
+
+    def sphere(spread):
+        return dict(kind="sphere", radius=float(rng.uniform(0.2, 1.4)), material=pick(),
+                    transform=[1, 0, 0, 0, 1, 0, 0, 0, 1] + rng.uniform(-spread, spread, 3).tolist())
+
+    def triangle(spread):
+        c = rng.uniform(-spread, spread, 3)
+        v = [(c + rng.uniform(-1.2, 1.2, 3)).tolist() for _ in range(3)]
+        return dict(kind="triangle", vertex1=v[0], vertex2=v[1], vertex3=v[2], material=pick())
+
+    nodes = []
+    for _ in range(int(rng.integers(1, 40))):
+        nodes.append(sphere(3.5))
+    for _ in range(int(rng.integers(0, 60))):
+        nodes.append(triangle(3.5))
+    for _ in range(int(rng.integers(0, 3))):
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        nodes.append(dict(kind="plane", normal=n.tolist(), distance=float(rng.uniform(-5.0, -2.0)), material=pick()))
+    for _ in range(int(rng.integers(0, 3))):
+        children = [sphere(1.5) for _ in range(int(rng.integers(0, 12)))] + [triangle(1.5) for _ in range(int(rng.integers(1, 30)))]
+        nodes.append(dict(kind="mesh", transform=_rotation(rng) + rng.uniform(-3.0, 3.0, 3).tolist(),
+                          bvh_type=int(rng.integers(1, 5)), bvh_order=int(rng.choice([2, 4, 8])), children=children,
+                          override_material=pick() if rng.random() < 0.3 else None))
+    return dict(bvh_order=8, default_bvh=int(rng.integers(1, 5)), materials=mats, nodes=nodes), rng
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scene(pta, rd, rd_wf, golden_dir, seed):
+    desc, rng = _random_description(1000 + seed)
+    scene = pta.scenes.scene_from_description(desc)
+    eye = rng.uniform(-1.0, 1.0, 3)
+    eye = eye / np.linalg.norm(eye) * rng.uniform(0.5, 9.0)  # sometimes inside the cloud of objects
+    scene.camera = pta.scene.PTCamera(transform=pta.godot_math.Transform3D.looking_at(tuple(eye.tolist()), (0.0, 0.0, 0.0)),
+                                      fov=float(rng.uniform(30.0, 90.0)))
+    _run_case(pta, rd, rd_wf, golden_dir, f"fuzz{seed}", 160, 96, int(rng.integers(1, 9)), int(rng.integers(0, 9)),
+              emission=bool(rng.random() < 0.3), dispatches=2, refraction_mode=int(rng.integers(0, 3)), scene=scene,
+              bvh_type=int(desc["default_bvh"]))
