@@ -141,15 +141,17 @@ int ptk_last_dispatch_ms(ptk_ctx* ctx, float* ms);
 int ptk_dispatch_history_ms(ptk_ctx* ctx, float* ms, int n);
 
 /* Schedule selection; no counterpart in the reference, where the driver's shader compiler owns the
- * schedule.  The library renders a dispatch either with one kernel that runs a pixel's whole bounce
- * loop (ray_tracer.comp:1553-1635 as written) or as a wavefront pipeline (one traversal launch and one
- * shading launch per bounce over ray queues in device memory).  Both produce the same image bit for
- * bit.  The pipeline covers plain render mode with the BVH flag set, no tracing, no early-t variant and
- * at most 32 bounces.  Where both apply, AUTO times each schedule on the first dispatches of a workload
- * (scene contents, group counts, depth limits) and keeps the faster one: the pipeline wins on heavy
- * scenes, the single kernel on light ones where per-bounce launches dominate.  WAVEFRONT makes
- * ptk_dispatch fail with PTK_E_UNSUPPORTED where the pipeline does not apply. */
-enum { PTK_RENDERER_AUTO = 0, PTK_RENDERER_SINGLE_KERNEL = 1, PTK_RENDERER_WAVEFRONT = 2 };
+ * schedule.  The library renders a dispatch in one of three ways, all producing the same image bit for
+ * bit: SINGLE_KERNEL, one kernel in which a lane runs a pixel's whole bounce loop and a wave is an 8x8
+ * tile (ray_tracer.comp:1553-1635 as written); WAVEFRONT, a pipeline with one traversal launch and one
+ * shading launch per bounce over ray queues in device memory; PERSISTENT, one kernel of persistent
+ * waves whose lanes take a new pixel as soon as their path ends.  WAVEFRONT and PERSISTENT cover plain
+ * render mode with the BVH flag set, no tracing and no early-t variant (WAVEFRONT: at most 32 bounces).
+ * Where several apply, AUTO times each on the first dispatches of a workload (scene contents, group
+ * counts, depth limits) and keeps the fastest: the pipeline wins on heavy scenes, the persistent kernel
+ * on light scenes whose paths differ in length, the tile kernel on light scenes whose paths do not.
+ * WAVEFRONT / PERSISTENT make ptk_dispatch fail with PTK_E_UNSUPPORTED where they do not apply. */
+enum { PTK_RENDERER_AUTO = 0, PTK_RENDERER_SINGLE_KERNEL = 1, PTK_RENDERER_WAVEFRONT = 2, PTK_RENDERER_PERSISTENT = 3 };
 int ptk_set_renderer(ptk_ctx* ctx, int renderer);
 /* Durations (ms) of the traversal-kernel launches of the dispatch `back` calls ago (0 = the last
  * one), from HIP events on the context's stream.  *n_launches = number of launches (0 when that

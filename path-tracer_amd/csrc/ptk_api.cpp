@@ -78,19 +78,20 @@ struct ptk_ctx {
     std::vector<int32_t> node_slot;  // node index -> block * 8 + child slot holding its box, -1 if none
     std::vector<int32_t> tri_slot, sph_slot;  // primitive index -> object-id slot holding its record, -1 if none
     long long full_validations = 0, patched_updates = 0;
-    // AUTO renderer choice: both schedules give the same image, so the first dispatches of a workload
-    // are used to time each of them (twice) and the faster one is kept until the workload changes
+    // AUTO renderer choice: all schedules give the same image, so the first dispatches of a workload
+    // are used to time each of them (twice) and the fastest one is kept until the workload changes
     struct AutoChoice {
         unsigned long long key = 0;       // what was timed: scene version, groups, depth limits, image
-        float best_ms[2] = {-1.0f, -1.0f};  // [0] one-kernel renderer, [1] wavefront pipeline
-        int samples[2] = {0, 0};
-        long long probe_dispatch[2] = {-1, -1};  // dispatch number of a timing still in flight
+        float best_ms[3] = {-1.0f, -1.0f, -1.0f};  // [0] one-kernel renderer, [1] wavefront pipeline, [2] persistent path kernel
+        int samples[3] = {0, 0, 0};
+        long long probe_dispatch[3] = {-1, -1, -1};  // dispatch number of a timing still in flight
     } auto_choice;
     unsigned long long scene_version = 0;
     float4* d_leaf_records = nullptr;  // per object-id slot: the primitive by value (48 bytes)
     void* d_wf = nullptr;          // queues + path state, one allocation
     size_t wf_slots = 0;
     int* d_wf_spill = nullptr;
+    uint32_t* d_pixel_counter = nullptr;  // persistent renderer: next pixel slot to hand out
     size_t wf_spill_ints = 0;
     int n_cus = 0;
     hipEvent_t* wf_ev[kTimingRing] = {nullptr};  // per dispatch slot: 2 events per traversal launch
@@ -190,6 +191,7 @@ void ptk_destroy(ptk_ctx* ctx) {
     if (ctx->d_leaf_records) (void)hipFree(ctx->d_leaf_records);
     if (ctx->d_wf) (void)hipFree(ctx->d_wf);
     if (ctx->d_wf_spill) (void)hipFree(ctx->d_wf_spill);
+    if (ctx->d_pixel_counter) (void)hipFree(ctx->d_pixel_counter);
     for (int i = 0; i < ptk_ctx::kTimingRing; i++) {
         if (ctx->wf_ev[i]) {
             for (int k = 0; k < 2 * PTK_WF_MAX_ITER; k++) (void)hipEventDestroy(ctx->wf_ev[i][k]);
@@ -838,19 +840,26 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
 
     const int slot = (int)(ctx->dispatch_count % ptk_ctx::kTimingRing);
 
-    // Which schedule renders this dispatch.  The wavefront pipeline covers the plain render mode over
-    // the BVH; BVH/normal views, brute force, the early-t variant and traced dispatches use the
-    // one-kernel renderer.  Both give the same image.
+    // Which schedule renders this dispatch.  The wavefront pipeline and the persistent path kernel cover
+    // the plain render mode over the BVH; BVH/normal views, brute force, the early-t variant and traced
+    // dispatches use the one-kernel renderer.  All three give the same image.
     const int fl = P.push.flags;
     const int rb_max = std::max(P.push.max_refraction_bounces - 1, 0);
     const int n_iter = P.push.max_default_depth + rb_max;  // most bounces any path can take (ray_tracer.comp:1572)
-    const bool wf_eligible = ctx->wf_ok && fl >= 0 && (fl & 1) && P.push.render_mode != 1 && P.push.render_mode != 2 &&
-                             !trace && !ctx->early_t_break && P.push.max_default_depth > 0 && n_iter <= PTK_WF_MAX_ITER;
-    if (ctx->renderer == PTK_RENDERER_WAVEFRONT && !wf_eligible)
-        return fail(ctx, PTK_E_UNSUPPORTED, "the wavefront renderer does not cover this dispatch (render mode, flags, tracing, early-t, depth > %d or nested mesh sockets)", PTK_WF_MAX_ITER);
-    bool use_wf = wf_eligible && ctx->renderer != PTK_RENDERER_SINGLE_KERNEL;
-    int probing = -1;  // this dispatch times renderer `probing` for the AUTO choice
-    if (wf_eligible && ctx->renderer == PTK_RENDERER_AUTO) {
+    const bool pp_eligible = ctx->wf_ok && fl >= 0 && (fl & 1) && P.push.render_mode != 1 && P.push.render_mode != 2 &&
+                             !trace && !ctx->early_t_break && P.push.max_default_depth > 0;
+    const bool wf_eligible = pp_eligible && n_iter <= PTK_WF_MAX_ITER;  // the pipeline launches once per bounce
+    int choice = 0;  // 0 one-kernel renderer, 1 wavefront pipeline, 2 persistent path kernel
+    if (ctx->renderer == PTK_RENDERER_WAVEFRONT) {
+        if (!wf_eligible)
+            return fail(ctx, PTK_E_UNSUPPORTED, "the wavefront renderer does not cover this dispatch (render mode, flags, tracing, early-t, depth > %d or nested mesh sockets)", PTK_WF_MAX_ITER);
+        choice = 1;
+    } else if (ctx->renderer == PTK_RENDERER_PERSISTENT) {
+        if (!pp_eligible)
+            return fail(ctx, PTK_E_UNSUPPORTED, "the persistent renderer does not cover this dispatch (render mode, flags, tracing, early-t, depth 0 or nested mesh sockets)");
+        choice = 2;
+    } else if (ctx->renderer == PTK_RENDERER_AUTO && pp_eligible) {
+        const bool eligible[3] = {true, wf_eligible, true};
         ptk_ctx::AutoChoice& ac = ctx->auto_choice;
         unsigned long long key = ctx->scene_version * 0x9E3779B97F4A7C15ull;
         for (unsigned long long v : {(unsigned long long)groups_x, (unsigned long long)groups_y, (unsigned long long)n_iter,
@@ -858,7 +867,7 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
                                      (unsigned long long)ctx->refraction_mode, (unsigned long long)ctx->use_emission})
             key = (key ^ v) * 0x100000001B3ull;
         if (key != ac.key) ac = ptk_ctx::AutoChoice(), ac.key = key;
-        for (int k = 0; k < 2; k++) {  // collect timings that have completed (never blocks)
+        for (int k = 0; k < 3; k++) {  // collect timings that have completed (never blocks)
             if (ac.probe_dispatch[k] < 0) continue;
             if (ctx->dispatch_count - ac.probe_dispatch[k] >= ptk_ctx::kTimingRing) { ac.probe_dispatch[k] = -1; continue; }
             const int ps = (int)(ac.probe_dispatch[k] % ptk_ctx::kTimingRing);
@@ -871,17 +880,60 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
             ac.probe_dispatch[k] = -1;
         }
         const int kProbes = 2;
-        if (ac.samples[0] < kProbes && ac.probe_dispatch[0] < 0) probing = 0;
-        else if (ac.samples[1] < kProbes && ac.probe_dispatch[1] < 0) probing = 1;
-        if (probing >= 0) { use_wf = probing == 1; ac.probe_dispatch[probing] = ctx->dispatch_count; }
-        else if (ac.samples[0] >= kProbes && ac.samples[1] >= kProbes) use_wf = ac.best_ms[1] <= ac.best_ms[0];
-        // (timings still in flight: the wavefront pipeline meanwhile)
+        int probing = -1;  // this dispatch times renderer `probing`
+        bool settled = true;
+        for (int k = 0; k < 3; k++) {
+            if (!eligible[k] || ac.samples[k] >= kProbes) continue;
+            settled = false;
+            if (probing < 0 && ac.probe_dispatch[k] < 0) probing = k;
+        }
+        if (probing >= 0) {
+            choice = probing;
+            ac.probe_dispatch[probing] = ctx->dispatch_count;
+        } else if (settled) {
+            for (int k = 1; k < 3; k++)
+                if (eligible[k] && ac.best_ms[k] < ac.best_ms[choice]) choice = k;
+        } else {
+            choice = 2;  // timings still in flight: the persistent kernel meanwhile
+        }
     }
 
-    if (!use_wf) {
+    if (choice == 0) {
         ctx->wf_iters[slot] = 0;
         HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
         HIP_TRY(ctx, ptk_launch_render(&P, groups_x, groups_y, trace, ctx->early_t_break, lds_bytes, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
+        ctx->dispatch_count++;
+        return PTK_OK;
+    }
+
+    if (choice == 2) {
+        const size_t pp_lds = (size_t)(P.lds_cap + 1) * 64 * 4;  // one spare row for rejected children
+        int waves_per_cu = 0;
+        HIP_TRY(ctx, ptk_persistent_occupancy(pp_lds, &waves_per_cu));
+        if (waves_per_cu <= 0) return fail(ctx, PTK_E_HIP, "the path kernel does not fit on a compute unit");
+        if (const char* cap = getenv("PTK_WF_WAVES_PER_CU")) waves_per_cu = std::max(1, std::min(waves_per_cu, atoi(cap)));  // tuning aid
+        const int n_waves = (int)std::min<size_t>((size_t)waves_per_cu * std::max(ctx->n_cus, 1), (lanes + 63) / 64);
+        if (!ctx->d_pixel_counter) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pixel_counter, 256));
+        P.wf.heads = ctx->d_pixel_counter;
+        P.wf.n_slots = (uint32_t)lanes;
+        P.wf.tiles_x = groups_x;
+        P.spill = nullptr;
+        P.spill_t = nullptr;
+        P.spill_stride = (size_t)n_waves * 64;
+        if (spill_entries > 0) {
+            size_t ints = (size_t)spill_entries * n_waves * 64;
+            if (ints > ctx->wf_spill_ints) {
+                if (ctx->d_wf_spill) { (void)hipFree(ctx->d_wf_spill); ctx->d_wf_spill = nullptr; }
+                ctx->wf_spill_ints = 0;
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->d_wf_spill, ints * 4));
+                ctx->wf_spill_ints = ints;
+            }
+            P.spill = ctx->d_wf_spill;
+        }
+        ctx->wf_iters[slot] = 0;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
+        HIP_TRY(ctx, ptk_launch_persistent(&P, pp_lds, n_waves, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
         ctx->dispatch_count++;
         return PTK_OK;
@@ -953,7 +1005,8 @@ int ptk_update_stats(ptk_ctx* ctx, long long* full_validations, long long* patch
 
 int ptk_set_renderer(ptk_ctx* ctx, int renderer) {
     if (!ctx) return PTK_E_INVALID;
-    if (renderer != PTK_RENDERER_AUTO && renderer != PTK_RENDERER_SINGLE_KERNEL && renderer != PTK_RENDERER_WAVEFRONT)
+    if (renderer != PTK_RENDERER_AUTO && renderer != PTK_RENDERER_SINGLE_KERNEL && renderer != PTK_RENDERER_WAVEFRONT &&
+        renderer != PTK_RENDERER_PERSISTENT)
         return fail(ctx, PTK_E_INVALID, "unknown renderer %d", renderer);
     ctx->renderer = renderer;
     return PTK_OK;

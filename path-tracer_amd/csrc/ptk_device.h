@@ -100,3 +100,5 @@ extern "C" hipError_t ptk_launch_render(const PtkParams* p, int gx, int gy, int 
 extern "C" hipError_t ptk_launch_wavefront(const PtkParams* p, int gx, int gy, int n_iter, size_t lds_bytes,
                                            int n_waves, hipEvent_t* ev, hipStream_t stream);
 extern "C" hipError_t ptk_wavefront_occupancy(size_t lds_bytes, int* waves_per_cu);
+extern "C" hipError_t ptk_launch_persistent(const PtkParams* p, size_t lds_bytes, int n_waves, hipStream_t stream);
+extern "C" hipError_t ptk_persistent_occupancy(size_t lds_bytes, int* waves_per_cu);

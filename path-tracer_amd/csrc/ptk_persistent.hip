@@ -1,0 +1,191 @@
+// ptk_persistent.hip -- the render path as one persistent kernel for gfx950 (CDNA4, wave64).
+//
+// A lane carries one pixel's path, as an invocation of the reference shader does
+// (shaders/ray_tracer.comp:1639-1705), but a wave is not tied to a tile: a lane whose path has ended
+// stores its pixel and takes the next pixel from a device-wide counter, so no lane idles until the
+// longest path of a tile is done, and nothing travels through queues in HBM between bounces.  A lane
+// is in one of three states -- idle (needs a pixel), searching (closest-hit search in progress, the
+// block traversal of ptk_render_core.h) or hit (search finished, the bounce of :1583-1621 is due) --
+// and the wave runs one kind of round at a time: an inner-node or leaf round for the searching lanes,
+// a bounce round once enough lanes wait for one, a refill round once enough lanes are idle.
+//
+// Per path the arithmetic and its order are those of the other two renderers (same device functions),
+// so the image has the same bits; only the order in which pixels are worked on differs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ptk_render_core.h"
+
+namespace {
+
+constexpr uint32_t PP_CHUNK = 64;  // pixels a wave claims per atomic
+#ifndef PTK_PP_BOUNCE
+#define PTK_PP_BOUNCE 48           // lanes waiting for their bounce that make the wave run a bounce round
+#endif
+#ifndef PTK_PP_REFILL
+#define PTK_PP_REFILL 16           // idle lanes that make the wave run a refill round
+#endif
+
+PTK_DEV int pp_rank_in(unsigned long long mask) {  // set bits of mask below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+enum : int { PP_IDLE = 0, PP_SEARCH = 1, PP_HIT = 2 };
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void ptk_path_kernel(const PtkParams P) {
+    extern __shared__ int lds_stack[];  // [entry][lane], P.lds_cap rows + one spare row
+    const int lane = threadIdx.x;
+    const PtkWavefront& W = P.wf;
+    Stack S;
+    S.lds = lds_stack; S.lane = lane; S.lds_cap = P.lds_cap; S.spill_stride = P.spill_stride;
+    S.spill = P.spill ? P.spill + (size_t)blockIdx.x * 64 + lane : nullptr;
+
+    const uint32_t n_slots = W.n_slots;  // pixel slots, tile-major: slot >> 6 = 8x8 tile, slot & 63 = pixel in it
+    uint32_t c_next = 0, c_end = 0;      // this wave's claimed range of slots
+    bool exhausted = n_slots == 0;
+
+    int phase = PP_IDLE;
+    uint32_t slot = 0;
+    int bounce = 0;
+    float4 color = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    Lane L;
+    L.current_IOR = 1.0f; L.inside_of_count = 0; L.seed = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAX_OVERLAP; i++) { L.in_mat[i] = 0; L.in_pri[i] = INT_NEG_LIMIT; }
+    L.is_emissive = 0; L.refraction_bounces = 0; L.ignore_attenuation = 0;
+    L.node_hit_count = 0; L.object_hit_count = 0;
+    Trav T;
+    T.o = mk3(0, 0, 0); T.d = mk3(0, 0, 1); T.start = 0.0f; T.end = 0.0f;
+    T.inv = mk3(0, 0, 0);
+    T.h.hit = 0; T.h.object_id = 0; T.h.transform_index = -1; T.h.u = 0.0f; T.h.v = 0.0f;
+    T.cur = ENTRY_NONE; T.sp = 0; T.sub_base = 0; T.cur_xf = -1;
+    T.w_o = mk3(0, 0, 0); T.w_d = mk3(0, 0, 1); T.w_start = 0.0f; T.dir_len = 1.0f;
+
+    for (;;) {
+        const bool searching = phase == PP_SEARCH;
+        const bool is_leaf = searching && trav_is_leaf(T);
+        const bool is_inner = searching && trav_is_inner(T);
+        const unsigned long long mi = __ballot(is_inner), ml = __ballot(is_leaf);
+        const bool none_searching = (mi | ml) == 0ull;
+        const int n_hit = __popcll(__ballot(phase == PP_HIT));
+        const int n_idle = __popcll(__ballot(phase == PP_IDLE));
+
+        if (n_hit > 0 && (none_searching || n_hit >= PTK_PP_BOUNCE)) {
+            // ---- bounce round: the loop body of cast_ray after the search (:1583-1621) ----
+            if (phase == PP_HIT) {
+                // the search ends at world level, so T.o / T.d are the segment's ray and T.end its hit distance
+                Ray nr;
+                nr.o = T.o; nr.d = T.d; nr.start = 0.0f; nr.end = T.end;
+                const Hit h = T.h;
+                bool done;
+                if (!h.hit) {
+                    const float4 sky = P.use_emission ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(0.7f, 0.7f, 0.9f, 1.0f);
+                    color = make_float4(color.x * sky.x, color.y * sky.y, color.z * sky.z, color.w * sky.w);
+                    done = true;
+                } else {
+                    Surf s = determine_rayhit<false>(P, L, nr, h, nullptr);
+                    if (P.use_emission && L.is_emissive) {
+                        color = make_float4(color.x * s.albedo.x, color.y * s.albedo.y, color.z * s.albedo.z, color.w * 1.0f);
+                        done = true;
+                    } else {
+                        const float4 tex_col = get_texture(P, s);
+                        nr = bounce_ray(P, L, nr, s);
+                        if (!L.ignore_attenuation) {
+                            color.x *= s.albedo.x * tex_col.x;
+                            color.y *= s.albedo.y * tex_col.y;
+                            color.z *= s.albedo.z * tex_col.z;
+                            color.w *= 1.0f * tex_col.w;
+                        } else {
+                            L.ignore_attenuation = 0;
+                        }
+                        bounce++;
+                        done = !(bounce < P.push.max_default_depth + L.refraction_bounces);
+                    }
+                }
+                if (done) {  // the end of main() (:1683-1704)
+                    if (P.use_emission && !L.is_emissive) color = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    const uint32_t tile = slot >> 6, l = slot & 63u;
+                    const int gx = (int)(tile % (uint32_t)W.tiles_x) * 8 + (int)(l & 7u);
+                    const int gy = (int)(tile / (uint32_t)W.tiles_x) * 8 + (int)(l >> 3);
+                    store_pixel(P, gx + P.push.image_offset_x, gy + P.push.image_offset_y, color, false, color);
+                    phase = PP_IDLE;
+                } else {
+                    trav_begin(P, T, nr);
+                    phase = T.cur == ENTRY_NONE ? PP_HIT : PP_SEARCH;  // (a ray that misses the root box has its result already)
+                }
+            }
+            continue;
+        }
+
+        if (!exhausted && n_idle > 0 && (none_searching || n_idle >= PTK_PP_REFILL)) {
+            // ---- refill round: idle lanes take the next pixels and start their paths (:1645-1681) ----
+#pragma unroll 1
+            for (int pass = 0; pass < 2 && !exhausted; pass++) {
+                const unsigned long long need = __ballot(phase == PP_IDLE);
+                if (need == 0ull) break;
+                if (c_next == c_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(W.heads, PP_CHUNK);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    c_next = base < n_slots ? base : n_slots;
+                    c_end = (base + PP_CHUNK) < n_slots ? (base + PP_CHUNK) : n_slots;
+                    if (c_next >= c_end) { exhausted = true; break; }
+                }
+                const uint32_t avail = c_end - c_next;
+                const uint32_t my = (uint32_t)pp_rank_in(need);
+                if (phase == PP_IDLE && my < avail) {
+                    slot = c_next + my;
+                    const uint32_t tile = slot >> 6, l = slot & 63u;
+                    const int gx = (int)(tile % (uint32_t)W.tiles_x) * 8 + (int)(l & 7u);
+                    const int gy = (int)(tile / (uint32_t)W.tiles_x) * 8 + (int)(l >> 3);
+                    const Primary pr = primary_ray(P.push, gx, gy);
+                    L.current_IOR = 1.0f; L.inside_of_count = 0; L.seed = pr.seed;
+#pragma unroll
+                    for (int i = 0; i < MAX_OVERLAP; i++) { L.in_mat[i] = 0; L.in_pri[i] = INT_NEG_LIMIT; }
+                    L.is_emissive = 0; L.refraction_bounces = 0; L.ignore_attenuation = 0;
+                    color = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                    bounce = 0;
+                    trav_begin(P, T, pr.ray);
+                    phase = T.cur == ENTRY_NONE ? PP_HIT : PP_SEARCH;
+                }
+                const uint32_t wanted = (uint32_t)__popcll(need);
+                c_next += wanted < avail ? wanted : avail;
+            }
+            continue;
+        }
+
+        if (none_searching) break;  // nothing to search, no bounce due, no pixel left to claim
+
+        // ---- search round: the larger group of searching lanes advances, the other waits ----
+        bool pop = false;
+        if (PTK_VOTE_INNER(__popcll(mi), __popcll(ml))) {
+            if (is_inner) pop = trav_inner(P, S, T);
+        } else {
+            trav_leaf(P, T, is_leaf);
+            pop = is_leaf;
+        }
+        if (pop) {
+            trav_pop(S, T);
+            if (T.cur == ENTRY_NONE) phase = PP_HIT;
+        }
+    }
+}
+
+extern "C" hipError_t ptk_persistent_occupancy(size_t lds_bytes, int* waves_per_cu) {
+    int n = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ptk_path_kernel, 64, lds_bytes);
+    if (e != hipSuccess) return e;
+    *waves_per_cu = n;
+    return hipSuccess;
+}
+
+// p->wf.heads points at the pixel counter (one word, cleared here); p->wf.n_slots / tiles_x describe the
+// dispatch; p->wf.blocks etc. the compiled scene.
+extern "C" hipError_t ptk_launch_persistent(const PtkParams* p, size_t lds_bytes, int n_waves, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(p->wf.heads, 0, 4, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ptk_path_kernel, dim3((unsigned)n_waves), dim3(64), lds_bytes, stream, *p);
+    return hipGetLastError();
+}

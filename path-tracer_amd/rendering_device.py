@@ -32,7 +32,7 @@ EXPORTS = [
     "ptk_set_renderer", "ptk_dispatch_traverse_ms", "ptk_update_stats",
 ]
 
-PTK_RENDERER_AUTO, PTK_RENDERER_SINGLE_KERNEL, PTK_RENDERER_WAVEFRONT = 0, 1, 2
+PTK_RENDERER_AUTO, PTK_RENDERER_SINGLE_KERNEL, PTK_RENDERER_WAVEFRONT, PTK_RENDERER_PERSISTENT = 0, 1, 2, 3
 
 _lib = None
 
@@ -256,7 +256,7 @@ class PtkRenderingDevice:
         return int(a.value), int(b.value)
 
     def set_renderer(self, renderer: int):
-        """PTK_RENDERER_AUTO / _SINGLE_KERNEL / _WAVEFRONT: the schedule used for the next dispatches."""
+        """PTK_RENDERER_AUTO / _SINGLE_KERNEL / _WAVEFRONT / _PERSISTENT: the schedule used for the next dispatches."""
         self._check(self.lib.ptk_set_renderer(self.ctx, int(renderer)), "ptk_set_renderer")
 
     def dispatch_traverse_ms(self, back: int = 0):

@@ -68,8 +68,9 @@ def test_empty_scene_is_all_sky(pta, rd, rd_wf, golden_dir):
 
 
 def test_wavefront_hands_over_outside_its_range(pta, rd, golden_dir):
-    """More than 32 bounces, or depth 0: AUTO renders with the one-kernel renderer (same image as the
-    oracle), and a context pinned to the wavefront pipeline reports the dispatch as unsupported."""
+    """More than 32 bounces, or depth 0: AUTO does not use the pipeline (same image as the oracle), and a
+    context pinned to the wavefront pipeline reports the dispatch as unsupported.  The persistent kernel has
+    no bound on the bounce count; depth 0 it refuses too."""
     wd = pta.work_dispatcher
     scene = pta.scenes.load_fixture_scene("sphere_scene3", golden_dir)
     packed = wd.pack_scene(scene, ob.OracleBvhBuilder(), 8)
@@ -94,6 +95,14 @@ def test_wavefront_hands_over_outside_its_range(pta, rd, golden_dir):
                 dev.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
                 with pytest.raises(pta.PtkError):
                     d.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
+                dev.set_renderer(pta.rendering_device.PTK_RENDERER_PERSISTENT)
+                if depth == 0:
+                    with pytest.raises(pta.PtkError):
+                        d.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
+                else:
+                    dev.texture_update(d.image_buffer, np.zeros((h, w, 4), np.float32))
+                    d.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
+                    _compare_image(f"depth{depth} persistent", dev.texture_get_data(d.image_buffer), cpu)
         d.free_rids()
     finally:
         dev.close()
@@ -121,7 +130,7 @@ def test_auto_renderer_settles_on_the_faster_schedule(pta, golden_dir):
             d.create_compute_list(win, scene.camera, t, sync=True)
             used.append(len(dev.dispatch_traverse_ms(0)) > 0)
             _compare_image(f"auto[{k}]", dev.texture_get_data(d.image_buffer), cpu)
-        assert True in used[:4] and False in used[:4], "both schedules are tried first"
+        assert True in used[:6] and False in used[:6], "every schedule is tried first (two dispatches each)"
         assert len(set(used[6:])) == 1, "then one of them is kept"
         d.free_rids()
     finally:

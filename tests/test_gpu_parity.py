@@ -20,11 +20,14 @@ def rd(pta):
     dev.close()
 
 
-@pytest.fixture(scope="module")
-def rd_wf(pta):
-    """A second context pinned to the wavefront renderer (untraced dispatches only)."""
+@pytest.fixture(scope="module", params=["wavefront", "persistent"])
+def rd_wf(pta, request):
+    """A second context pinned to one of the two schedules that cover untraced plain dispatches: the
+    wavefront pipeline or the persistent path kernel.  Every test that takes it runs once with each."""
     dev = pta.PtkRenderingDevice(0)
-    dev.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
+    dev.pinned = request.param
+    dev.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT if request.param == "wavefront"
+                     else pta.rendering_device.PTK_RENDERER_PERSISTENT)
     yield dev
     dev.close()
 
@@ -78,8 +81,8 @@ def _run_case(pta, rd, rd_wf, golden_dir, name, w, h, depth, bounces, emission=F
                      rd.trace_read_counters(disp.image_buffer), out["pixel_stats"])
             if disp_wf is not None:
                 disp_wf.create_compute_list(win, scene.camera, t, sync=True)
-                assert len(rd_wf.dispatch_traverse_ms(0)) > 0, "the wavefront renderer did not run"
-                _compare_image(f"{name}[{k}] wavefront", rd_wf.texture_get_data(disp_wf.image_buffer), cpu_img)
+                assert (len(rd_wf.dispatch_traverse_ms(0)) > 0) == (rd_wf.pinned == "wavefront"), "the pinned renderer did not run"
+                _compare_image(f"{name}[{k}] {rd_wf.pinned}", rd_wf.texture_get_data(disp_wf.image_buffer), cpu_img)
     finally:
         rd.trace_enable(0)
         disp.free_rids()

@@ -37,7 +37,7 @@ def test_edits_between_samples(pta, rd, rd_wf, golden_dir, scene_name):
     packed = copy.copy(wd.pack_scene(scene, ob.OracleBvhBuilder(), 8))
     w, h = 320, 184
     devs = []
-    for name, dev in (("one-kernel", rd), ("wavefront", rd_wf)):
+    for name, dev in (("one-kernel", rd), (rd_wf.pinned, rd_wf)):
         d = wd.PTWorkDispatcher(dev)
         d.create_buffers(w, h, packed=packed)
         d.load_shader()

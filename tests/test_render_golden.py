@@ -29,7 +29,7 @@ def test_oracle_reproduces_recorded_images(case, golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("renderer", [1, 2], ids=["one-kernel", "wavefront"])
+@pytest.mark.parametrize("renderer", [1, 2, 3], ids=["one-kernel", "wavefront", "persistent"])
 @pytest.mark.parametrize("case", GOLDEN["cases"], ids=IDS)
 def test_gpu_reproduces_recorded_images(pta, case, renderer, golden_dir):
     """Same fixtures through the C ABI, BVH built on the GPU, no oracle involved at run time."""
