@@ -17,8 +17,8 @@ CASES = [  # label, scene, width, height, depth, refraction bounces, use_emissio
     ("C5 atrium 262144 tris, 1080p", "atrium", 1920, 1080, 8, 4, False),
     ("C5 atrium 262144 tris, 4K", "atrium", 3840, 2160, 8, 4, False),
 ]
-print("| configuration | rays per sample | one-kernel ms | pipeline ms | Mrays/s (faster) |")
-print("|---|---|---|---|---|")
+print("| configuration | rays per sample | tile kernel ms | pipeline ms | persistent kernel ms | Mrays/s (fastest) |")
+print("|---|---|---|---|---|---|")
 atrium = None
 for label, name, w, h, depth, bounces, emission in CASES:
     if name == "atrium":
@@ -38,7 +38,7 @@ for label, name, w, h, depth, bounces, emission in CASES:
     rays = int(rd.trace_read_counters(disp.image_buffer).reshape(-1, RD.PTK_NCOUNTERS).sum(0)[RD.COUNTER_NAMES.index("rays")])
     rd.trace_enable(0)
     ms = {}
-    for r in (RD.PTK_RENDERER_SINGLE_KERNEL, RD.PTK_RENDERER_WAVEFRONT):
+    for r in (RD.PTK_RENDERER_SINGLE_KERNEL, RD.PTK_RENDERER_WAVEFRONT, RD.PTK_RENDERER_PERSISTENT):
         rd.set_renderer(r)
         for k in range(8):
             win.frame = k
@@ -46,7 +46,7 @@ for label, name, w, h, depth, bounces, emission in CASES:
         rd.sync()
         ms[r] = float(np.median(rd.dispatch_history_ms(6)))
     best = min(ms.values())
-    print("| %s, %dx%d, depth %d | %.2f M | %.3f | %.3f | %.0f |" % (label, w, h, depth, rays / 1e6, ms[RD.PTK_RENDERER_SINGLE_KERNEL],
-                                                                 ms[RD.PTK_RENDERER_WAVEFRONT], rays / best / 1e3))
+    print("| %s, %dx%d, depth %d | %.2f M | %.3f | %.3f | %.3f | %.0f |" % (label, w, h, depth, rays / 1e6, ms[RD.PTK_RENDERER_SINGLE_KERNEL],
+                                                                        ms[RD.PTK_RENDERER_WAVEFRONT], ms[RD.PTK_RENDERER_PERSISTENT], rays / best / 1e3))
     disp.free_rids()
     rd.close()
