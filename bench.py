@@ -176,6 +176,32 @@ def main():
     kernel_ms = rd.dispatch_history_ms(n_hist)
     traverse_ms = [rd.dispatch_traverse_ms(back) for back in range(n_hist)]  # per dispatch: one duration per launch
 
+    # The other partitioning (N > 1 only, reported beside the contract's figures): every rank renders its band
+    # of tile rows of the SAME samples and rank 0 gathers the bands -- strong scaling of one frame, bit-identical
+    # to a one-GPU render.
+    tile_partition = None
+    if world > 1:
+        band = mg.band_window(win, rank, world)
+
+        def run_bands(n):
+            for k in range(n):
+                band.frame = k
+                disp.create_compute_list(band, scene.camera, wd.sample_time(k))
+            rd.image_copy_device(disp.image_buffer, reduce_buf.data_ptr(), reduce_buf.numel() * 4, to_image=False)
+            mg.gather_bands(reduce_buf, HEIGHT // 8, dst=0)
+            rd.sync()
+
+        run_bands(1)
+        barrier()
+        t_band = time.perf_counter()
+        run_bands(args.steps)
+        barrier()
+        band_s = time.perf_counter() - t_band
+        tb = torch.tensor([band_s], dtype=torch.float64, device=f"cuda:{device_index}")
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        tile_partition = {"ms_per_frame": float(tb[0].item()) / args.steps * 1e3, "frames": args.steps,
+                          "partitioning": "contiguous bands of 8-pixel tile rows per GPU, one gather of the bands per batch"}
+
     rays_total = rays_local
     if world > 1:
         t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=f"cuda:{device_index}")
@@ -237,6 +263,9 @@ def main():
                      "bytes_per_ray": step_bytes * args.steps / max(rays_local, 1)},
         },
     }
+
+    if tile_partition is not None:
+        out["tile_partition"] = tile_partition
 
     if not args.no_cpu_baseline and world == 1:
         # CPU baseline: the oracle (a restatement of ray_tracer.comp, not Godot/lavapipe, which do not
