@@ -7,7 +7,7 @@
 // is in one of three states -- idle (needs a pixel), searching (closest-hit search in progress, the
 // block traversal of ptk_render_core.h) or hit (search finished, the bounce of :1583-1621 is due) --
 // and the wave runs one kind of round at a time: an inner-node or leaf round for the searching lanes,
-// a bounce round once enough lanes wait for one, a refill round once enough lanes are idle.
+// a bounce round once the waiting lanes outnumber the searching ones, a refill round once enough lanes are idle.
 //
 // Per path the arithmetic and its order are those of the other two renderers (same device functions),
 // so the image has the same bits; only the order in which pixels are worked on differs.
@@ -19,8 +19,10 @@
 namespace {
 
 constexpr uint32_t PP_CHUNK = 64;  // pixels a wave claims per atomic
-#ifndef PTK_PP_BOUNCE
-#define PTK_PP_BOUNCE 48           // lanes waiting for their bounce that make the wave run a bounce round
+#ifndef PTK_PP_BOUNCE_NOW
+// a bounce round runs once the lanes waiting for their bounce are as many as the lanes still searching
+// (the same majority rule as between inner and leaf rounds); measured against fixed thresholds of 16..64
+#define PTK_PP_BOUNCE_NOW(n_hit, n_search) ((n_hit) >= (n_search))
 #endif
 #ifndef PTK_PP_REFILL
 #define PTK_PP_REFILL 16           // idle lanes that make the wave run a refill round
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(64) void ptk_path_kernel(const PtkParams P) {
         const int n_hit = __popcll(__ballot(phase == PP_HIT));
         const int n_idle = __popcll(__ballot(phase == PP_IDLE));
 
-        if (n_hit > 0 && (none_searching || n_hit >= PTK_PP_BOUNCE)) {
+        if (n_hit > 0 && (none_searching || PTK_PP_BOUNCE_NOW(n_hit, __popcll(mi | ml)))) {
             // ---- bounce round: the loop body of cast_ray after the search (:1583-1621) ----
             if (phase == PP_HIT) {
                 // the search ends at world level, so T.o / T.d are the segment's ray and T.end its hit distance
