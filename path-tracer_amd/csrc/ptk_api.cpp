@@ -278,7 +278,7 @@ int ptk_buffer_update(ptk_ctx* ctx, uint64_t buffer, size_t offset, const void* 
     const int patched = patch_derived(ctx, o, offset, nbytes, before);
     if (patched < 0) { ctx->dirty = true; return patched; }
     if (patched == 0) ctx->dirty = true;
-    else { ctx->patched_updates++; ctx->scene_version++; }
+    else ctx->patched_updates++;  // (the AUTO renderer choice stays: topology and sizes are as they were timed)
     return PTK_OK;
 }
 
