@@ -135,3 +135,52 @@ def test_auto_renderer_settles_on_the_faster_schedule(pta, golden_dir):
         d.free_rids()
     finally:
         dev.close()
+
+
+def test_hand_made_tree_with_wide_leaves(pta, rd, rd_wf, golden_dir):
+    """Node bytes a caller wrote by hand rather than PTBVHTree: a root with two leaves of 100 and 28 objects
+    (the format allows up to 128 per leaf, ray_tracer.comp:600-606; the plugin's builder stops at `order`)."""
+    import copy
+    import struct
+
+    wd, sc, gm = pta.work_dispatcher, pta.scene, pta.godot_math
+    rng = np.random.default_rng(5)
+    scene = sc.PTScene()
+    glass = sc.PTMaterial(opacity=0.0, IOR=1.5, dielectric_priority=1)
+    red = sc.PTMaterial(albedo=(0.8, 0.2, 0.2))
+    for i in range(128):
+        scene.add_object(sc.PTSphere(transform=gm.Transform3D(origin=tuple(rng.uniform(-3.0, 3.0, 3).tolist())),
+                                     radius=float(rng.uniform(0.1, 0.6)), material=glass if i % 3 == 0 else red))
+    scene.camera = sc.PTCamera(transform=gm.Transform3D.looking_at((0.0, 1.0, 9.0), (0.0, 0.0, 0.0)), fov=50.0)
+    packed = copy.copy(wd.pack_scene(scene, ob.OracleBvhBuilder(), 8))
+
+    def node(lo, hi, node_id, xf=-1):
+        return struct.pack("<3fi3fi", lo, lo, lo, node_id, hi, hi, hi, xf)
+
+    def leaf_id(first_slot, count):
+        return ((-first_slot - 1) ^ ((count - 1) << 24)) & 0xFFFFFFFF
+
+    to_i32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v  # noqa: E731
+    nodes = node(-4.0, 4.0, 1 ^ (2 << 24)) + node(-4.0, 4.0, to_i32(leaf_id(0, 100))) + node(-4.0, 4.0, to_i32(leaf_id(100, 28)))
+    packed.bvh = wd.create_bvh_byte_array(nodes)
+    packed.object_ids = np.array([i | (1 << 24) for i in range(128)], np.int32).tobytes()
+    w, h = 160, 96
+    cpu = np.zeros((h, w, 4), np.float32)
+    disps = []
+    for dev in (rd, rd_wf):
+        d = wd.PTWorkDispatcher(dev)
+        d.create_buffers(w, h, packed=packed)
+        d.load_shader()
+        disps.append((dev, d))
+    try:
+        for k in range(2):
+            win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=6, max_refraction_bounces=6)
+            win.frame = k
+            t = wd.sample_time(k)
+            ob.render(packed, wd.push_constant_bytes(scene.camera, win, t), cpu, w // 8, h // 8)
+            for dev, d in disps:
+                d.create_compute_list(win, scene.camera, t, sync=True)
+                _compare_image(f"wide-leaves[{k}]", dev.texture_get_data(d.image_buffer), cpu)
+    finally:
+        for _, d in disps:
+            d.free_rids()
