@@ -83,3 +83,23 @@ def test_random_scene(pta, rd, rd_wf, golden_dir, seed):
     _run_case(pta, rd, rd_wf, golden_dir, f"fuzz{seed}", 160, 96, int(rng.integers(1, 9)), int(rng.integers(0, 9)),
               emission=bool(rng.random() < 0.3), dispatches=2, refraction_mode=int(rng.integers(0, 3)), scene=scene,
               bvh_type=int(desc["default_bvh"]))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_singular_mesh_transform(pta, rd, rd_wf, golden_dir, seed):
+    """A mesh squashed flat (one scale factor 0): its inverse matrix holds Inf / NaN, so rays that reach the
+    mesh socket get NaN directions and ranges.  Whatever the shader's arithmetic makes of that, the HIP
+    renderers make the same of it as the oracle (NaN texels must be NaN on both sides)."""
+    desc, rng = _random_description(2000 + seed)
+    children = [dict(kind="sphere", radius=0.7, material="m1", transform=[1, 0, 0, 0, 1, 0, 0, 0, 1, 0.2, 0.1, 0.0])]
+    for _ in range(12):
+        c = rng.uniform(-1.0, 1.0, 3)
+        children.append(dict(kind="triangle", vertex1=(c + rng.uniform(-1, 1, 3)).tolist(), vertex2=(c + rng.uniform(-1, 1, 3)).tolist(),
+                             vertex3=(c + rng.uniform(-1, 1, 3)).tolist(), material="m2"))
+    basis = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0]
+    basis[4 * (seed % 3)] = 0.0  # zero scale on one axis
+    desc["nodes"].append(dict(kind="mesh", transform=basis + [0.0, 0.0, 0.0], bvh_type=4, bvh_order=8, children=children))
+    with np.errstate(all="ignore"):
+        scene = pta.scenes.scene_from_description(desc)
+        scene.camera = pta.scene.PTCamera(transform=pta.godot_math.Transform3D.looking_at((1.0, 2.0, 7.0), (0.0, 0.0, 0.0)), fov=60.0)
+        _run_case(pta, rd, rd_wf, golden_dir, f"singular{seed}", 160, 96, 5, 4, dispatches=2, scene=scene, bvh_type=int(desc["default_bvh"]))
