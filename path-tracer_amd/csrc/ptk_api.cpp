@@ -29,7 +29,7 @@ struct Object {
     int set = -1, binding = -1;
     int width = 0, height = 0, slot = -1;
     std::vector<uint8_t> shadow;  // host copy of storage buffers (validation, derived tables)
-    std::unique_ptr<PtkBvh> bvh;
+    std::shared_ptr<PtkBvh> bvh;  // shared with every scene tree that merged it as a mesh
 };
 
 struct Slot {
@@ -94,6 +94,9 @@ struct ptk_ctx {
     uint32_t* d_pixel_counter = nullptr;  // persistent renderer: next pixel slot to hand out
     size_t wf_spill_ints = 0;
     int n_cus = 0;
+    int lds_window = 32;           // traversal stack entries per lane kept in LDS (PTK_LDS_WINDOW, read once at create)
+    int waves_per_cu_cap = 0;      // > 0: upper bound on persistent waves per CU (PTK_WF_WAVES_PER_CU, read once at create)
+    int wf_waves_per_cu = 0, pp_waves_per_cu = 0;  // occupancy of the two persistent kernels for the bound scene's LDS need
     hipEvent_t* wf_ev[kTimingRing] = {nullptr};  // per dispatch slot: 2 events per traversal launch
     int wf_iters[kTimingRing] = {0};            // traversal launches of that dispatch (0: one-kernel renderer)
     // tracing
@@ -160,6 +163,9 @@ ptk_ctx* ptk_create(int device_ordinal) {
     hipDeviceProp_t prop;
     ok = ok && hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess;
     if (ok) ctx->n_cus = prop.multiProcessorCount;
+    // development knobs are read here once: a variable that appears in the host's environment later changes nothing
+    if (const char* w = getenv("PTK_LDS_WINDOW")) ctx->lds_window = std::max(8, std::min(64, atoi(w)));
+    if (const char* c = getenv("PTK_WF_WAVES_PER_CU")) ctx->waves_per_cu_cap = std::max(1, atoi(c));
     if (!ok) {
         fail(nullptr, PTK_E_HIP, "stream/event creation failed");
         delete ctx;
@@ -682,6 +688,16 @@ static int validate_scene(ptk_ctx* ctx) {
 
     { int r = refresh_live_planes(ctx, pln); if (r != PTK_OK) return r; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // persistent waves per CU of both persistent kernels at this scene's LDS need (window + one spare row)
+    {
+        const size_t lds = (size_t)(std::min(ctx->stack_need, ctx->lds_window) + 1) * 64 * 4;
+        HIP_TRY(ctx, ptk_wavefront_occupancy(lds, &ctx->wf_waves_per_cu));
+        HIP_TRY(ctx, ptk_persistent_occupancy(lds, &ctx->pp_waves_per_cu));
+        if (ctx->waves_per_cu_cap > 0) {
+            ctx->wf_waves_per_cu = std::min(ctx->wf_waves_per_cu, ctx->waves_per_cu_cap);
+            ctx->pp_waves_per_cu = std::min(ctx->pp_waves_per_cu, ctx->waves_per_cu_cap);
+        }
+    }
     ctx->dirty = false;
     ctx->full_validations++;
     ctx->scene_version++;
@@ -733,18 +749,18 @@ int ptk_trace_read(ptk_ctx* ctx, int which, void* dst, size_t nbytes) {
     return PTK_OK;
 }
 
-int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, int groups_z) {
-    if (!ctx) return PTK_E_INVALID;
+// Argument checks shared by the dispatch entry points.
+static int check_dispatch_args(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, int groups_z) {
     if (!push128) return fail(ctx, PTK_E_INVALID, "push constants missing");
     if (groups_x <= 0 || groups_y <= 0 || groups_z != 1 || groups_x > 65535 || groups_y > 65535)
         return fail(ctx, PTK_E_INVALID, "bad group counts (%d,%d,%d); depth must be 1", groups_x, groups_y, groups_z);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return PTK_OK;
+}
+
+// Kernel parameters from the push constants and the bound, validated scene (ctx->dirty must be false).
+static int fill_params(ptk_ctx* ctx, const void* push128, PtkParams& P) {
     Object* img = find(ctx, ctx->image, Kind::Image);
     if (!img) return fail(ctx, PTK_E_STATE, "no image bound at (0,0)");
-    if (ctx->dirty) { int r = validate_scene(ctx); if (r != PTK_OK) return r; }
-    if (ctx->textures_dirty) { int r = refresh_textures(ctx); if (r != PTK_OK) return r; }
-
-    PtkParams P;
     memset(&P, 0, sizeof P);
     memcpy(&P.push, push128, 128);
     if (P.push.max_default_depth < 0 || P.push.max_default_depth > 4096 || P.push.max_refraction_bounces < 0 || P.push.max_refraction_bounces > 4096)
@@ -756,6 +772,8 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     Object* pln = bound_buffer(ctx, PTK_SET_OBJECT, 2);
     Object* tri = bound_buffer(ctx, PTK_SET_OBJECT, 3);
     Object* xf = bound_buffer(ctx, PTK_SET_TRANSFORM, 0);
+    if (!nodes || !ids || !mats || !sph || !pln || !tri || !xf)
+        return fail(ctx, PTK_E_STATE, "dispatch needs buffers at (2,0..3), (3,0..1) and (6,0)");
     P.nodes = (const float4*)nodes->dev;
     P.object_ids = (const int*)ids->dev;
     P.materials = (const float4*)mats->dev;
@@ -777,12 +795,43 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     memcpy(P.proc_builtin, ctx->proc_builtin, sizeof P.proc_builtin);
     P.refraction_mode = ctx->refraction_mode;
     P.use_emission = ctx->use_emission;
+    return PTK_OK;
+}
+
+// The compiled node blocks and leaf records of the bound scene (PtkWavefront), for the block traversal.
+static void fill_blocks(const ptk_ctx* ctx, PtkParams& P) {
+    P.wf.blocks = ctx->d_blocks;
+    P.wf.sockets = ctx->d_sockets;
+    P.wf.root_min_x = ctx->root_box[0]; P.wf.root_min_y = ctx->root_box[1]; P.wf.root_min_z = ctx->root_box[2];
+    P.wf.root_max_x = ctx->root_box[3]; P.wf.root_max_y = ctx->root_box[4]; P.wf.root_max_z = ctx->root_box[5];
+    P.wf.root_entry = ctx->root_entry;
+    P.wf.n_blocks = ctx->n_blocks; P.wf.n_sockets = ctx->n_sockets; P.wf.n_records = ctx->n_records;
+    P.wf.leaf_records = ctx->d_leaf_records;
+}
+
+// Whether the persistent path kernel (and, within its bounce limit, the wavefront pipeline) covers a
+// dispatch: plain render mode over the BVH, untraced, no early-t variant, at least one bounce.
+static bool persistent_covers(const ptk_ctx* ctx, const PtkPush& push, bool trace) {
+    const int fl = push.flags;
+    return ctx->wf_ok && fl >= 0 && (fl & 1) && push.render_mode != 1 && push.render_mode != 2 && !trace &&
+           !ctx->early_t_break && push.max_default_depth > 0;
+}
+
+int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, int groups_z) {
+    if (!ctx) return PTK_E_INVALID;
+    { int r = check_dispatch_args(ctx, push128, groups_x, groups_y, groups_z); if (r != PTK_OK) return r; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Object* img = find(ctx, ctx->image, Kind::Image);
+    if (!img) return fail(ctx, PTK_E_STATE, "no image bound at (0,0)");
+    if (ctx->dirty) { int r = validate_scene(ctx); if (r != PTK_OK) return r; }
+    if (ctx->textures_dirty) { int r = refresh_textures(ctx); if (r != PTK_OK) return r; }
+
+    PtkParams P;
+    { int r = fill_params(ctx, push128, P); if (r != PTK_OK) return r; }
 
     // traversal stack: an LDS window per lane plus a global spill column for deeper entries
-    int kLdsWindow = 32;
-    if (const char* w = getenv("PTK_LDS_WINDOW")) kLdsWindow = std::max(8, std::min(64, atoi(w)));  // tuning aid
     const int need = ctx->stack_need;
-    P.lds_cap = std::min(need, kLdsWindow);
+    P.lds_cap = std::min(need, ctx->lds_window);
     const size_t lanes = (size_t)groups_x * groups_y * 64;
     if (lanes > ((size_t)1 << 30)) return fail(ctx, PTK_E_UNSUPPORTED, "dispatch of %zu invocations; at most 2^30 per dispatch", lanes);
     P.spill_stride = lanes;
@@ -828,26 +877,16 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
 
     // the compiled node blocks and leaf records: read by the wavefront pipeline and by the untraced
     // one-kernel renderer (null: that renderer walks the bound node buffer itself)
-    if (ctx->wf_ok && !trace && !ctx->early_t_break) {
-        P.wf.blocks = ctx->d_blocks;
-        P.wf.sockets = ctx->d_sockets;
-        P.wf.root_min_x = ctx->root_box[0]; P.wf.root_min_y = ctx->root_box[1]; P.wf.root_min_z = ctx->root_box[2];
-        P.wf.root_max_x = ctx->root_box[3]; P.wf.root_max_y = ctx->root_box[4]; P.wf.root_max_z = ctx->root_box[5];
-        P.wf.root_entry = ctx->root_entry;
-        P.wf.n_blocks = ctx->n_blocks; P.wf.n_sockets = ctx->n_sockets; P.wf.n_records = ctx->n_records;
-        P.wf.leaf_records = ctx->d_leaf_records;
-    }
+    if (ctx->wf_ok && !trace && !ctx->early_t_break) fill_blocks(ctx, P);
 
     const int slot = (int)(ctx->dispatch_count % ptk_ctx::kTimingRing);
 
     // Which schedule renders this dispatch.  The wavefront pipeline and the persistent path kernel cover
     // the plain render mode over the BVH; BVH/normal views, brute force, the early-t variant and traced
     // dispatches use the one-kernel renderer.  All three give the same image.
-    const int fl = P.push.flags;
     const int rb_max = std::max(P.push.max_refraction_bounces - 1, 0);
     const int n_iter = P.push.max_default_depth + rb_max;  // most bounces any path can take (ray_tracer.comp:1572)
-    const bool pp_eligible = ctx->wf_ok && fl >= 0 && (fl & 1) && P.push.render_mode != 1 && P.push.render_mode != 2 &&
-                             !trace && !ctx->early_t_break && P.push.max_default_depth > 0;
+    const bool pp_eligible = persistent_covers(ctx, P.push, trace != 0);
     const bool wf_eligible = pp_eligible && n_iter <= PTK_WF_MAX_ITER;  // the pipeline launches once per bounce
     int choice = 0;  // 0 one-kernel renderer, 1 wavefront pipeline, 2 persistent path kernel
     if (ctx->renderer == PTK_RENDERER_WAVEFRONT) {
@@ -909,10 +948,8 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
 
     if (choice == 2) {
         const size_t pp_lds = (size_t)(P.lds_cap + 1) * 64 * 4;  // one spare row for rejected children
-        int waves_per_cu = 0;
-        HIP_TRY(ctx, ptk_persistent_occupancy(pp_lds, &waves_per_cu));
+        const int waves_per_cu = ctx->pp_waves_per_cu;
         if (waves_per_cu <= 0) return fail(ctx, PTK_E_HIP, "the path kernel does not fit on a compute unit");
-        if (const char* cap = getenv("PTK_WF_WAVES_PER_CU")) waves_per_cu = std::max(1, std::min(waves_per_cu, atoi(cap)));  // tuning aid
         const int n_waves = (int)std::min<size_t>((size_t)waves_per_cu * std::max(ctx->n_cus, 1), (lanes + 63) / 64);
         if (!ctx->d_pixel_counter) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pixel_counter, 256));
         P.wf.heads = ctx->d_pixel_counter;
@@ -966,10 +1003,8 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     }
     // persistent traversal waves: as many as fit on the device at once
     const size_t wf_lds = (size_t)(P.lds_cap + 1) * 64 * 4;  // one spare row for rejected children
-    int waves_per_cu = 0;
-    HIP_TRY(ctx, ptk_wavefront_occupancy(wf_lds, &waves_per_cu));
+    const int waves_per_cu = ctx->wf_waves_per_cu;
     if (waves_per_cu <= 0) return fail(ctx, PTK_E_HIP, "the traversal kernel does not fit on a compute unit");
-    if (const char* cap = getenv("PTK_WF_WAVES_PER_CU")) waves_per_cu = std::max(1, std::min(waves_per_cu, atoi(cap)));  // tuning aid
     const int n_waves = (int)std::min<size_t>((size_t)waves_per_cu * std::max(ctx->n_cus, 1), (n_slots + 63) / 64);
     P.spill = nullptr;
     P.spill_t = nullptr;
@@ -1064,19 +1099,19 @@ uint64_t ptk_bvh_build(ptk_ctx* ctx, int order, int type, int n_objects, const f
     if (type < PTK_BVH_X_SORTED || type > PTK_BVH_XYZ_SORTED) { fail(ctx, PTK_E_INVALID, "unknown BVH type %d", type); return 0; }
     if (n_objects < 0 || n_meshes < 0 || n_objects + n_meshes <= 0) { fail(ctx, PTK_E_INVALID, "cannot create bvh without objects or meshes"); return 0; }
     if (n_objects > 0 && (!aabbs6 || !object_ids)) { fail(ctx, PTK_E_INVALID, "object arrays missing"); return 0; }
-    std::vector<PtkBvh*> subs;
+    std::vector<std::shared_ptr<PtkBvh>> subs;
     for (int m = 0; m < n_meshes; m++) {
         Object* o = mesh_bvhs ? find(ctx, mesh_bvhs[m], Kind::Bvh) : nullptr;
         if (!o || !o->bvh) { fail(ctx, PTK_E_INVALID, "mesh %d: unknown BVH handle", m); return 0; }
         if (o->bvh->adopted) { fail(ctx, PTK_E_INVALID, "mesh %d: BVH already merged into another tree", m); return 0; }
-        subs.push_back(o->bvh.get());
+        subs.push_back(o->bvh);
     }
     if (n_meshes > 0 && (!mesh_transforms12 || !mesh_indices)) { fail(ctx, PTK_E_INVALID, "mesh arrays missing"); return 0; }
     std::string err;
-    std::unique_ptr<PtkBvh> bvh = ptk_bvh_build_device(ctx->stream, order, type, n_objects, aabbs6, object_ids, subs,
+    std::shared_ptr<PtkBvh> bvh = ptk_bvh_build_device(ctx->stream, order, type, n_objects, aabbs6, object_ids, subs,
                                                       mesh_transforms12, mesh_indices, err);
     if (!bvh) { fail(ctx, PTK_E_UNSUPPORTED, "bvh build failed: %s", err.c_str()); return 0; }
-    for (PtkBvh* s : subs) s->adopted = true;
+    for (auto& s : subs) s->adopted = true;
     auto o = std::make_unique<Object>();
     o->kind = Kind::Bvh;
     o->bvh = std::move(bvh);

@@ -550,7 +550,7 @@ struct BvhImpl : PtkBvh {
     int n_objects = 0, n_in = 0;
     std::vector<HNode> nodes;          // node 0 = root
     std::vector<int> leaf_order;       // index_node order of this tree's own leaves
-    std::vector<BvhImpl*> meshes;      // adopted sub-trees (owned elsewhere, kept alive by their handles)
+    std::vector<std::shared_ptr<BvhImpl>> meshes;  // adopted sub-trees, shared with the handles they were built under
     std::vector<int> mesh_index;       // transform index of each mesh
     DevBuf<float> in_aabb;             // n_in boxes
     DevBuf<int> in_kind, in_ref;       // 0 object / 1 socket; object id
@@ -561,14 +561,15 @@ struct BvhImpl : PtkBvh {
     int own_nodes() const { return (int)nodes.size(); }
     int flat_node_count() const override {
         int n = own_nodes();
-        for (auto* m : meshes) n += m->flat_node_count();
+        for (auto& m : meshes) n += m->flat_node_count();
         return n;
     }
     int flat_id_count() const override {
         int n = own_object_count;
-        for (auto* m : meshes) n += m->flat_id_count();
+        for (auto& m : meshes) n += m->flat_id_count();
         return n;
     }
+    int mesh_count() const override { return (int)meshes.size(); }
     bool flatten(hipStream_t stream, uint8_t* node_bytes, int32_t* object_ids, std::string& err) override;
 };
 
@@ -893,7 +894,7 @@ bool BvhImpl::flatten(hipStream_t st, uint8_t* node_bytes, int32_t* object_ids, 
     flat.reserve(total);
     // per tree: offset of its boxes in the concatenated box buffer, offset of its ids in the id table
     std::vector<BvhImpl*> trees = {this};
-    for (auto* m : meshes) trees.push_back(m);
+    for (auto& m : meshes) trees.push_back(m.get());
     std::vector<int> box_off(trees.size()), id_off(trees.size());
     int bo = 0, io = 0;
     for (size_t t = 0; t < trees.size(); t++) { box_off[t] = bo; bo += trees[t]->own_nodes(); id_off[t] = io; io += trees[t]->own_object_count; }
@@ -911,7 +912,7 @@ bool BvhImpl::flatten(hipStream_t st, uint8_t* node_bytes, int32_t* object_ids, 
     auto children_of = [&](Ref r, std::vector<Ref>& out) {
         out.clear();
         const HNode& nd = r.tree->nodes[r.node];
-        if (nd.kind == N_SOCKET) out.push_back({meshes[nd.mesh_slot], 0});
+        if (nd.kind == N_SOCKET) out.push_back({meshes[nd.mesh_slot].get(), 0});
         else for (int c : nd.children) out.push_back({r.tree, c});
     };
     {
@@ -992,18 +993,20 @@ bool BvhImpl::flatten(hipStream_t st, uint8_t* node_bytes, int32_t* object_ids, 
     return true;
 }
 
-std::unique_ptr<PtkBvh> ptk_bvh_build_device(hipStream_t stream, int order, int type, int n_objects,
+std::shared_ptr<PtkBvh> ptk_bvh_build_device(hipStream_t stream, int order, int type, int n_objects,
                                              const float* aabbs6, const int32_t* object_ids,
-                                             const std::vector<PtkBvh*>& mesh_trees,
+                                             const std::vector<std::shared_ptr<PtkBvh>>& mesh_trees,
                                              const float* mesh_transforms12, const int32_t* mesh_indices,
                                              std::string& err) {
     if (order > MAXB) { err = "the device builder bins for order <= 8"; return nullptr; }
-    auto T = std::make_unique<BvhImpl>();
+    auto T = std::make_shared<BvhImpl>();
     T->order = order;
     T->type = type;
     T->n_objects = n_objects;
     for (size_t m = 0; m < mesh_trees.size(); m++) {
-        T->meshes.push_back(static_cast<BvhImpl*>(mesh_trees[m]));
+        // flatten() resolves one level of sockets: a mesh tree with sockets of its own is refused
+        if (!mesh_trees[m] || mesh_trees[m]->mesh_count() != 0) { err = "a mesh tree must not contain mesh sockets itself"; return nullptr; }
+        T->meshes.push_back(std::static_pointer_cast<BvhImpl>(mesh_trees[m]));
         T->mesh_index.push_back(mesh_indices[m]);
     }
     if (!build_tree(stream, *T, aabbs6, object_ids, mesh_transforms12, err)) return nullptr;

@@ -179,6 +179,12 @@ class DeviceBvhBuilder:
     def read(self, handle):
         return self.rd.bvh_read(handle)
 
+    def release(self, scene_handle, mesh_handles=()):
+        """Frees the trees' handles (and with them the builder's device buffers) once their bytes are read."""
+        self.rd.free_rid(scene_handle)
+        for h in mesh_handles:
+            self.rd.free_rid(h)
+
 
 def _object_lists(spheres: Sequence[sc.PTSphere], triangles, scene: sc.PTScene):
     """AABBs and object ids in create_disconnected_node_list order (spheres, then triangles)."""
@@ -221,7 +227,10 @@ def create_scene_bvh(scene: sc.PTScene, builder, order: int = 8, bvh_type: Optio
     if aabbs.shape[0] == 0 and not mesh_handles:
         return None, None
     h = builder.build(order, bvh_type, aabbs, ids, mesh_handles, mesh_t, mesh_i)
-    return builder.read(h)
+    try:
+        return builder.read(h)
+    finally:
+        builder.release(h, mesh_handles)
 
 
 def create_bvh_byte_array(node_bytes: Optional[bytes], buffer_size: int = 0) -> bytes:

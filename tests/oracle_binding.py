@@ -193,6 +193,10 @@ class OracleBvhBuilder:
     def free(self, t):
         self.lib.pbo_free(t)
 
+    def release(self, scene_handle, mesh_handles=()):
+        """pbo_free releases a scene tree together with the mesh trees merged into it."""
+        self.lib.pbo_free(scene_handle)
+
 
 def algorithmic_bytes(totals, n_planes_padded: int, pixels: int) -> int:
     """Algorithmic bytes of one dispatch in the reference's AoS layout, no cache credit:

@@ -123,3 +123,34 @@ def test_builder_errors(pta, rd):
         rd.bvh_build(1, 1, np.ones((2, 6), np.float32), np.zeros(2, np.int32))
     with pytest.raises(pta.PtkError):
         rd.bvh_build(8, 9, np.ones((2, 6), np.float32), np.zeros(2, np.int32))
+
+
+def test_scene_tree_outlives_its_mesh_handles(pta, rd):
+    """A scene tree shares ownership of the mesh trees merged into it: freeing a mesh's handle before the
+    scene tree is read changes nothing, and a mesh tree with mesh sockets of its own is refused."""
+    sc = pta.scene
+    rng = np.random.default_rng(2)
+    tris = (rng.uniform(-1, 1, (500, 1, 3)) + rng.normal(0, 0.1, (500, 3, 3))).astype(np.float32)
+    ts = sc.PTTriangleSet(vertices=tris)
+    aabbs = ts.bvh_aabbs()
+    ids = (np.arange(500, dtype=np.int32)) + np.int32(3 << 24)
+    sph_aabb = np.array([[2.0, 2.0, 2.0, 1.0, 1.0, 1.0]], np.float32)
+    sph_id = np.array([1 << 24], np.int32)
+    t12 = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.5, 0.0, -0.5]
+
+    oracle = ob.OracleBvhBuilder()
+    om = oracle.build(8, 4, aabbs, ids)
+    ot = oracle.build(8, 1, sph_aabb, sph_id, [om], [t12], [0])
+    cpu_nodes, cpu_ids = oracle.read(ot)
+    oracle.release(ot)
+
+    mesh = rd.bvh_build(8, 4, aabbs, ids)
+    tree = rd.bvh_build(8, 1, sph_aabb, sph_id, [mesh], [t12], [0])
+    with pytest.raises(pta.PtkError):
+        rd.bvh_build(8, 1, sph_aabb, sph_id, [tree], [t12], [0])  # a tree with sockets cannot be a mesh
+    rd.free_rid(mesh)  # the scene tree keeps the mesh tree alive
+    gpu_nodes, gpu_ids = rd.bvh_read(tree)
+    _check("mesh handle freed first", cpu_nodes, cpu_ids, gpu_nodes, gpu_ids)
+    gpu_nodes, gpu_ids = rd.bvh_read(tree)  # and again: reading is repeatable
+    _check("second read", cpu_nodes, cpu_ids, gpu_nodes, gpu_ids)
+    rd.free_rid(tree)
