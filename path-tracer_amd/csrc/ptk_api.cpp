@@ -155,6 +155,11 @@ ptk_ctx* ptk_create(int device_ordinal) {
         fail(nullptr, PTK_E_HIP, "hipSetDevice(%d) failed", device_ordinal);
         return nullptr;
     }
+    // ptk_dispatch_noalloc's static scratch: resolve this device's copy of the array now (the device is current)
+    if (hipError_t se = ptk_persistent_scratch_init(device_ordinal); se != hipSuccess) {
+        fail(nullptr, PTK_E_HIP, "hipGetSymbolAddress of the static scratch array failed on device %d: %s", device_ordinal, hipGetErrorString(se));
+        return nullptr;
+    }
     auto* ctx = new ptk_ctx();
     ctx->device = device_ordinal;
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
@@ -1026,6 +1031,58 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     ctx->wf_iters[slot] = n_iter;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
     HIP_TRY(ctx, ptk_launch_wavefront(&P, groups_x, groups_y, n_iter, wf_lds, n_waves, ctx->wf_ev[slot], ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
+    ctx->dispatch_count++;
+    return PTK_OK;
+}
+
+// ptk_dispatch for callers that must not allocate: the persistent path kernel with its pixel counter and
+// stack-spill column in the library's static device array instead of hipMalloc'ed buffers.  Calls no
+// hipMalloc / hipFree / allocating routine: anything that would need one is an error instead.
+int ptk_dispatch_noalloc(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, int groups_z) {
+    if (!ctx) return PTK_E_INVALID;
+    { int r = check_dispatch_args(ctx, push128, groups_x, groups_y, groups_z); if (r != PTK_OK) return r; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->dirty || ctx->textures_dirty)
+        return fail(ctx, PTK_E_STATE, "the bound scene changed since the last ptk_dispatch: its derived tables are rebuilt (and allocated) "
+                                      "there; call ptk_dispatch once, then ptk_dispatch_noalloc");
+    PtkParams P;
+    { int r = fill_params(ctx, push128, P); if (r != PTK_OK) return r; }
+    if (ctx->trace_flags != 0 || !persistent_covers(ctx, P.push, false))
+        return fail(ctx, PTK_E_UNSUPPORTED, "ptk_dispatch_noalloc covers the plain render mode over the BVH only (no tracing, debug views, "
+                                            "brute force, early-t variant, depth 0 or nested mesh sockets)");
+    const size_t lanes = (size_t)groups_x * groups_y * 64;
+    if (lanes > ((size_t)1 << 30)) return fail(ctx, PTK_E_UNSUPPORTED, "dispatch of %zu invocations; at most 2^30 per dispatch", lanes);
+    uint8_t* const scratch_ptr = (uint8_t*)ptk_persistent_scratch(ctx->device);
+    if (!scratch_ptr) return fail(ctx, PTK_E_STATE, "the static scratch array was not resolved on device %d", ctx->device);
+    fill_blocks(ctx, P);
+    P.lds_cap = std::min(ctx->stack_need, ctx->lds_window);
+    const size_t pp_lds = (size_t)(P.lds_cap + 1) * 64 * 4;
+    if (ctx->pp_waves_per_cu <= 0) return fail(ctx, PTK_E_HIP, "the path kernel does not fit on a compute unit");
+    size_t n_waves = std::min<size_t>((size_t)ctx->pp_waves_per_cu * std::max(ctx->n_cus, 1), (lanes + 63) / 64);
+    // stack entries past the LDS window: one int per entry and lane, [entry][wave * 64 + lane], behind the counter line
+    const int spill_entries = ctx->stack_need - P.lds_cap;
+    const size_t spill_room = PTK_NOALLOC_SCRATCH_BYTES - 256;
+    if (spill_entries > 0) {
+        // fewer persistent waves need a smaller column (the image does not depend on their number), but
+        // below one wave per compute unit the dispatch is refused rather than crawled through
+        const size_t fit = spill_room / ((size_t)spill_entries * 64 * 4);
+        const size_t floor_waves = std::min<size_t>((size_t)std::max(ctx->n_cus, 1), (lanes + 63) / 64);
+        if (fit < floor_waves)
+            return fail(ctx, PTK_E_UNSUPPORTED, "the bound BVH can need %d traversal-stack entries per ray; the static scratch of %zu bytes "
+                                                "holds at most %zu beyond the %d kept on chip for this dispatch: use ptk_dispatch",
+                        ctx->stack_need, (size_t)PTK_NOALLOC_SCRATCH_BYTES, spill_room / (floor_waves * 64 * 4), P.lds_cap);
+        n_waves = std::min(n_waves, fit);
+        P.spill = (int*)(scratch_ptr + 256);
+    }
+    P.spill_stride = n_waves * 64;
+    P.wf.heads = (uint32_t*)scratch_ptr;  // cleared by the launch below: the array keeps the last call's contents
+    P.wf.n_slots = (uint32_t)lanes;
+    P.wf.tiles_x = groups_x;
+    const int slot = (int)(ctx->dispatch_count % ptk_ctx::kTimingRing);
+    ctx->wf_iters[slot] = 0;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
+    HIP_TRY(ctx, ptk_launch_persistent(&P, pp_lds, (int)n_waves, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
     ctx->dispatch_count++;
     return PTK_OK;

@@ -102,3 +102,8 @@ extern "C" hipError_t ptk_launch_wavefront(const PtkParams* p, int gx, int gy, i
 extern "C" hipError_t ptk_wavefront_occupancy(size_t lds_bytes, int* waves_per_cu);
 extern "C" hipError_t ptk_launch_persistent(const PtkParams* p, size_t lds_bytes, int n_waves, hipStream_t stream);
 extern "C" hipError_t ptk_persistent_occupancy(size_t lds_bytes, int* waves_per_cu);
+// Static device scratch of ptk_dispatch_noalloc (a file-scope __device__ array in ptk_persistent.hip):
+// [0, 256) pixel counter, the rest traversal-stack spill.  _init resolves the current device's copy once.
+#define PTK_NOALLOC_SCRATCH_BYTES ((size_t)8 << 20)
+extern "C" hipError_t ptk_persistent_scratch_init(int device);
+extern "C" void* ptk_persistent_scratch(int device);

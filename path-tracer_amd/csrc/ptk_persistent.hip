@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "ptk_render_core.h"
 
 namespace {
@@ -175,6 +177,40 @@ __global__ __launch_bounds__(64) void ptk_path_kernel(const PtkParams P) {
     }
 }
 
+// ---- static scratch for ptk_dispatch_noalloc --------------------------------------------------------
+// The path kernel needs two pieces of device memory beyond the scene and the image: the pixel counter
+// its waves claim work from, and the spill column for traversal-stack entries past the LDS window.
+// ptk_dispatch takes both from hipMalloc; ptk_dispatch_noalloc, for callers that must not allocate,
+// takes them from this array.  Every GPU the library runs on holds its own copy for the life of the
+// process.  Layout: bytes [0, 256) the pixel counter, the rest the spill column.
+static __device__ __align__(256) unsigned char scratch[PTK_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices] = {nullptr};  // device address of `scratch` on each GPU (the array's name is not one)
+std::mutex g_scratch_mutex;
+}  // namespace
+
+// Resolves this device's copy of the scratch array.  Call with `device` current; repeated calls are cheap.
+extern "C" hipError_t ptk_persistent_scratch_init(int device) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    void* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = ptr;
+    return hipSuccess;
+}
+
+// Device address of the scratch array on `device` (null before ptk_persistent_scratch_init succeeded there).
+extern "C" void* ptk_persistent_scratch(int device) {
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    return g_scratch_ptr[device];
+}
+
 extern "C" hipError_t ptk_persistent_occupancy(size_t lds_bytes, int* waves_per_cu) {
     int n = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ptk_path_kernel, 64, lds_bytes);
@@ -183,10 +219,10 @@ extern "C" hipError_t ptk_persistent_occupancy(size_t lds_bytes, int* waves_per_
     return hipSuccess;
 }
 
-// p->wf.heads points at the pixel counter (one word, cleared here); p->wf.n_slots / tiles_x describe the
-// dispatch; p->wf.blocks etc. the compiled scene.
+// p->wf.heads points at the pixel counter (the first word of a 256-byte line, cleared here); p->wf.n_slots /
+// tiles_x describe the dispatch; p->wf.blocks etc. the compiled scene.
 extern "C" hipError_t ptk_launch_persistent(const PtkParams* p, size_t lds_bytes, int n_waves, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(p->wf.heads, 0, 4, stream);
+    hipError_t e = hipMemsetAsync(p->wf.heads, 0, 256, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ptk_path_kernel, dim3((unsigned)n_waves), dim3(64), lds_bytes, stream, *p);
     return hipGetLastError();

@@ -29,7 +29,7 @@ EXPORTS = [
     "ptk_buffer_read", "ptk_image_create", "ptk_image_read", "ptk_image_update", "ptk_texture_create",
     "ptk_dispatch", "ptk_sync", "ptk_free", "ptk_bvh_build", "ptk_bvh_sizes", "ptk_bvh_read",
     "ptk_trace_enable", "ptk_trace_read", "ptk_last_dispatch_ms", "ptk_dispatch_history_ms", "ptk_image_copy_device",
-    "ptk_set_renderer", "ptk_dispatch_traverse_ms", "ptk_update_stats",
+    "ptk_set_renderer", "ptk_dispatch_traverse_ms", "ptk_update_stats", "ptk_dispatch_noalloc",
 ]
 
 PTK_RENDERER_AUTO, PTK_RENDERER_SINGLE_KERNEL, PTK_RENDERER_WAVEFRONT, PTK_RENDERER_PERSISTENT = 0, 1, 2, 3
@@ -74,6 +74,8 @@ def load_library() -> C.CDLL:
     lib.ptk_texture_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     lib.ptk_dispatch.restype = C.c_int
     lib.ptk_dispatch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    lib.ptk_dispatch_noalloc.restype = C.c_int
+    lib.ptk_dispatch_noalloc.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
     lib.ptk_sync.restype = C.c_int
     lib.ptk_sync.argtypes = [vp]
     lib.ptk_free.restype = C.c_int
@@ -196,6 +198,11 @@ class PtkRenderingDevice:
     def compute_list_dispatch(self, push_bytes: bytes, x: int, y: int, z: int = 1):
         assert len(push_bytes) == 128
         self._check(self.lib.ptk_dispatch(self.ctx, push_bytes, x, y, z), "ptk_dispatch")
+
+    def compute_list_dispatch_noalloc(self, push_bytes: bytes, x: int, y: int, z: int = 1):
+        """The same dispatch through the entry point that allocates nothing (static device scratch)."""
+        assert len(push_bytes) == 128
+        self._check(self.lib.ptk_dispatch_noalloc(self.ctx, push_bytes, x, y, z), "ptk_dispatch_noalloc")
 
     def sync(self):
         self._check(self.lib.ptk_sync(self.ctx), "ptk_sync")
