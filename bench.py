@@ -8,9 +8,12 @@ one path segment = one closest-hit search (check_ray_hit_BVH, shaders/ray_tracer
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 runs under torch.distributed.run, one process per GPU: the scene is replicated, every rank
-renders its own batch of K samples of the full frame (weak scaling) and the per-GPU accumulation
-images are combined once per batch with an RCCL reduce inside the timed region.
+N > 1 runs one process per GPU: the scene is replicated, every rank renders its own batch of K samples
+of the full frame (weak scaling) and the per-GPU accumulation images are combined once per batch with
+an RCCL reduce inside the timed region.  Under torch.distributed.run (WORLD_SIZE set) the process is one
+rank; started plainly with --gpus N it launches torch.distributed.run itself, before anything touches
+the GPU, and passes the ranks' output through.  On a box with fewer than N GPUs the ranks share GPU 0 and
+talk over gloo (a rehearsal of the control flow, marked "rehearsal": true in the line).
 
 A step is rendered by the wavefront pipeline: one generate launch, then per bounce one traversal
 launch (ptk_wf_traverse, the dominant kernel) and one shading launch.
@@ -70,6 +73,15 @@ def measured_traffic(workload):
     return t.get("traverse_bytes_per_launch")
 
 
+def limiter_note():
+    """What the committed PMC passes show to bound the traversal kernel (profiles/traffic.json, key "limiter")."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get("limiter")
+    except (OSError, ValueError):
+        return None
+
+
 def reference_runtime_note():
     """The shader itself could only be timed by Godot 4.3 on a CPU Vulkan driver (lavapipe); say whether
     this host has them (it never runs them: the oracle is the baseline that is timed)."""
@@ -90,18 +102,35 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the ranks ourselves.  This process has imported neither torch nor the
+        # HIP library yet, so it only waits for the children; rank 0 prints the JSON line.
+        import socket
+        import subprocess
+
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("PTK_BENCH_PRINT_LAUNCH") == "1":
+            print(json.dumps(cmd))
+            return
+        raise SystemExit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} under a launcher needs --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
 
     import torch
     import torch.distributed as dist
 
-    # Rehearsal on a one-GPU box (PTK_BENCH_REHEARSAL=1): every rank uses GPU 0 and the process group runs
-    # over gloo, which exercises the same control flow (batches, reduce, copy-back, timing) without RCCL.
-    rehearsal = os.environ.get("PTK_BENCH_REHEARSAL") == "1"
+    # Rehearsal (fewer GPUs than ranks, or PTK_BENCH_REHEARSAL=1): every rank uses GPU 0 and the process group
+    # runs over gloo, which exercises the same control flow (batches, reduce, copy-back, timing) without RCCL.
+    rehearsal = os.environ.get("PTK_BENCH_REHEARSAL") == "1" or (world > 1 and torch.cuda.device_count() < world)
     device_index = 0 if (rehearsal or world == 1) else local_rank
     if world > 1:
         torch.cuda.set_device(device_index)
@@ -133,8 +162,11 @@ def main():
     # --- untimed: count the rays and traversal work of exactly the K timed steps (traced kernel variant)
     rd.trace_enable(pta.rendering_device.PTK_TRACE_COUNTERS)
     counters = np.zeros(pta.rendering_device.PTK_NCOUNTERS, dtype=np.int64)
+    # frame numbers of a batch: the plugin's 0..K-1 on one GPU; 1..K on several, where every rank's running
+    # mix must keep all of its samples for the reduce to give the mean of all N*K (multi_gpu.batch_frame)
+    first_frame = mg.batch_frame(0) if world > 1 else 0
     for k in range(args.steps):
-        win.frame = k
+        win.frame = first_frame + k
         disp.create_compute_list(win, scene.camera, wd.sample_time(sample_index(k)), sync=True)
         counters += rd.trace_read_counters(disp.image_buffer).reshape(-1, pta.rendering_device.PTK_NCOUNTERS).sum(0)
     rd.trace_enable(0)
@@ -147,7 +179,7 @@ def main():
     if world > 1:
         reduce_buf = torch.empty((HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{device_index}")
 
-    def run_steps(n, first_frame=0):
+    def run_steps(n):
         for k in range(n):
             win.frame = first_frame + k
             disp.create_compute_list(win, scene.camera, wd.sample_time(sample_index(k)))
@@ -230,8 +262,9 @@ def main():
     achieved_gbs = trav_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     step_bytes = algorithmic_bytes(cnt, n_planes_padded, pixels * args.steps) / args.steps
     step_gbs = step_bytes / (avg_step_ms * 1e-3) / 1e9
+    traffic = measured_traffic(workload)
     out = {
-        "metric": "Mrays/s (path segments/s) at 1920x1080 Sponza",
+        "metric": "Mrays/s (path segments/s) at 1920x1080 Sponza (synthetic 262144-triangle stand-in: the reference's .blend is not in its checkout)",
         "value": rays_total / elapsed / 1e6,
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -250,6 +283,7 @@ def main():
             "bvh_nodes": len(disp.packed.bvh) // 32, "bvh_build_s": build_s,
             "parallelism": "sample batches per GPU, scene replicated, RCCL reduce of accumulators" if world > 1 else "single GPU",
         },
+        **({"rehearsal": True, "rehearsal_note": "ranks share GPU 0 and reduce over gloo: control flow only, not a scaling figure"} if rehearsal and world > 1 else {}),
         "roofline": {
             "bound": "hbm",
             "kernel": "ptk_wf_traverse",
@@ -257,7 +291,12 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
-            "traffic": measured_traffic(workload),
+            "traffic": traffic,
+            # `achieved` prices the reference layout's bytes with no cache credit, as the metric is defined; what
+            # the memory side really moved per launch, and the units that limit the kernel, are stated beside it
+            "hbm_measured": None if traffic is None else {"bytes_per_launch": traffic, "gbs": traffic / (avg_launch_ms * 1e-3) / 1e9,
+                                                          "frac_of_peak": traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "limiter": limiter_note(),
             "bytes_per_launch": trav_bytes_per_launch,
             "launch_ms_avg": avg_launch_ms,
             "launches_per_step": launches_per_step,

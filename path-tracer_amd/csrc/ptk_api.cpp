@@ -75,6 +75,10 @@ struct ptk_ctx {
     uint32_t n_blocks = 0, n_sockets = 0, n_records = 0;
     // host mirrors and maps of the derived structures, for patching them on buffer_update
     std::vector<float> h_blocks, h_leaf_records;
+    std::vector<int32_t> h_sockets;  // {entry of the mesh's root, transform index} per world-level socket
+    uint32_t tree_entry = 0;         // the root node's own entry (root_entry is what follows the chain)
+    int n_chain = 0;
+    PtkChainStep chain[PTK_MAX_CHAIN];
     std::vector<int32_t> node_slot;  // node index -> block * 8 + child slot holding its box, -1 if none
     std::vector<int32_t> tri_slot, sph_slot;  // primitive index -> object-id slot holding its record, -1 if none
     long long full_validations = 0, patched_updates = 0;
@@ -96,7 +100,8 @@ struct ptk_ctx {
     int n_cus = 0;
     int lds_window = 32;           // traversal stack entries per lane kept in LDS (PTK_LDS_WINDOW, read once at create)
     int waves_per_cu_cap = 0;      // > 0: upper bound on persistent waves per CU (PTK_WF_WAVES_PER_CU, read once at create)
-    int wf_waves_per_cu = 0, pp_waves_per_cu = 0;  // occupancy of the two persistent kernels for the bound scene's LDS need
+    int wf_wgs_per_cu = 0, pp_waves_per_cu = 0;  // occupancy of the two persistent kernels for the bound scene's LDS need
+    uint32_t n_top = 0;            // blocks [0, n_top): top of the tree, breadth-first, LDS-resident in the traversal kernel
     hipEvent_t* wf_ev[kTimingRing] = {nullptr};  // per dispatch slot: 2 events per traversal launch
     int wf_iters[kTimingRing] = {0};            // traversal launches of that dispatch (0: one-kernel renderer)
     // tracing
@@ -137,6 +142,7 @@ static Object* bound_buffer(ptk_ctx* ctx, int set, int binding) {
 }
 
 static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, const std::vector<uint8_t>& before);
+static void derive_chain(ptk_ctx* ctx);
 
 extern "C" {
 
@@ -515,9 +521,46 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
             }
         }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        derive_chain(ctx);  // a patched box may be one of the chain's
         return 1;
     }
     return 0;  // object ids and anything else: rebuild
+}
+
+// The steps every search takes at the top of the tree before it reaches a node with a choice
+// (PtkWavefront::chain): from the root's entry, while the next node is an inner node with exactly one child
+// (a box test) or a world-level mesh socket.  Reads the host mirrors of the compiled blocks, so it is run
+// again whenever they are patched.
+static void derive_chain(ptk_ctx* ctx) {
+    uint32_t e = ctx->tree_entry;
+    int n = 0;
+    if (ctx->wf_ok) {
+        while (n < PTK_MAX_CHAIN) {
+            PtkChainStep& c = ctx->chain[n];
+            if ((e & 0xFF000000u) == 0x7F000000u) {  // mesh socket
+                const size_t si = e & 0x00FFFFFFu;
+                if (si * 2 + 1 >= ctx->h_sockets.size()) break;
+                memset(&c, 0, sizeof c);
+                c.kind = 1;
+                c.xf = ctx->h_sockets[si * 2 + 1];
+                e = (uint32_t)ctx->h_sockets[si * 2];
+            } else if ((int32_t)e > 0 && (e >> 24) == 1u) {  // inner node with one child
+                const size_t b = e & 0x00FFFFFFu;
+                if ((b + 1) * 64 > ctx->h_blocks.size()) break;
+                const float* blk = ctx->h_blocks.data() + b * 64;
+                c.lo[0] = blk[0]; c.lo[1] = blk[8]; c.lo[2] = blk[16];
+                c.hi[0] = blk[24]; c.hi[1] = blk[32]; c.hi[2] = blk[40];
+                c.kind = 0;
+                c.xf = -1;
+                memcpy(&e, blk + 48, 4);
+            } else {
+                break;
+            }
+            n++;
+        }
+    }
+    ctx->n_chain = n;
+    ctx->root_entry = e;
 }
 
 // Walks the node buffer exactly as the kernel will and checks every index it
@@ -618,29 +661,55 @@ static int validate_scene(ptk_ctx* ctx) {
     // and entries of one inner node's children; blocks are numbered parent first, depth first.
     std::vector<float>& blocks = ctx->h_blocks;
     blocks.clear();
-    std::vector<int32_t> sockets;
+    std::vector<int32_t>& sockets = ctx->h_sockets;
+    sockets.clear();
     ctx->node_slot.assign((size_t)n_nodes, -1);
+    ctx->n_top = 0;
     if (wf_ok) {
+        // Block numbers: the top of the tree first, breadth-first from the root (through world-level mesh
+        // sockets into the meshes), as many blocks as the traversal kernel's LDS has room for beside its
+        // stack windows; everything below in depth-first order, parent first.
+        std::vector<int32_t> block_of((size_t)n_nodes, -1);
+        uint32_t next_free = 0;
+        {
+            const size_t stacks = (size_t)PTK_WF_WG_WAVES * (std::min(ctx->stack_need, ctx->lds_window) + 1) * 256;
+            const size_t room = PTK_LDS_BYTES_PER_CU > stacks ? (PTK_LDS_BYTES_PER_CU - stacks) / PTK_TOP_BLOCK_STRIDE : 0;
+            const size_t limit = std::min<size_t>(room, 480);
+            std::vector<std::pair<int, bool>> queue = {{0, false}};  // node, inside a mesh
+            for (size_t q = 0; q < queue.size() && next_free < limit; q++) {
+                const int i = queue[q].first;
+                const bool in_mesh = queue[q].second;
+                const int id = nv.node_id(i);
+                const int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
+                if (idx <= 0) continue;  // leaf
+                if (nv.xform(i) >= 0 && !in_mesh) { queue.push_back({idx, true}); continue; }  // socket: its child is the mesh's root
+                block_of[i] = (int32_t)next_free++;
+                for (int l = 0; l < size; l++) queue.push_back({idx + l, in_mesh});
+            }
+            ctx->n_top = next_free;
+        }
         struct Compiler {
             const NodeView& nv; std::vector<float>& blocks; std::vector<int32_t>& sockets; std::vector<int32_t>& node_slot;
-            uint32_t compile(int i, bool in_mesh) {
+            const std::vector<int32_t>& block_of; uint32_t& next_free;
+            uint32_t compile(int i, bool in_mesh, int depth = 0) {
                 const int id = nv.node_id(i);
                 const int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
                 const int x = nv.xform(i);
                 if (idx <= 0) return (uint32_t)id;  // leaf
                 if (x >= 0 && !in_mesh) {           // world-level socket: its child is the mesh's root
-                    const uint32_t child = compile(idx, true);
+                    const uint32_t child = compile(idx, true, depth);
                     const int sidx = (int)(sockets.size() / 2);
                     sockets.push_back((int32_t)child);
                     sockets.push_back(x);
                     return 0x7F000000u | (uint32_t)sidx;
                 }
-                const size_t b = blocks.size() / 64;
-                blocks.resize(blocks.size() + 64, 0.0f);
+                const size_t b = block_of[i] >= 0 ? (size_t)block_of[i] : (size_t)next_free++;
+                if (blocks.size() < (b + 1) * 64) blocks.resize((b + 1) * 64, 0.0f);
+                memcpy(blocks.data() + b * 64 + 56, &depth, 4);  // first spare word: the block's depth (measurement builds read it)
                 for (int l = 0; l < size; l++) {
                     float box[8];
                     memcpy(box, nv.p + (size_t)(idx + l) * 32, 32);
-                    const uint32_t e = compile(idx + l, in_mesh || x >= 0);
+                    const uint32_t e = compile(idx + l, in_mesh || x >= 0, depth + 1);
                     float* blk = blocks.data() + b * 64;  // (re-read: compile() may have grown the vector)
                     blk[0 + l] = box[0]; blk[8 + l] = box[1]; blk[16 + l] = box[2];
                     blk[24 + l] = box[4]; blk[32 + l] = box[5]; blk[40 + l] = box[6];
@@ -649,12 +718,14 @@ static int validate_scene(ptk_ctx* ctx) {
                 }
                 return (uint32_t)b | ((uint32_t)size << 24);
             }
-        } compiler{nv, blocks, sockets, ctx->node_slot};
-        ctx->root_entry = compiler.compile(0, false);
+        } compiler{nv, blocks, sockets, ctx->node_slot, block_of, next_free};
+        blocks.resize((size_t)next_free * 64, 0.0f);
+        ctx->tree_entry = compiler.compile(0, false);
         memcpy(ctx->root_box, nv.p, 12);
         memcpy(ctx->root_box + 3, nv.p + 16, 12);
         if (blocks.size() / 64 > 0x00FFFFFF) ctx->wf_ok = false;
     }
+    derive_chain(ctx);
     ctx->n_blocks = (uint32_t)(blocks.size() / 64);
     ctx->n_sockets = (uint32_t)(sockets.size() / 2);
     ctx->n_records = (uint32_t)std::max(n_ids, 0);
@@ -696,12 +767,9 @@ static int validate_scene(ptk_ctx* ctx) {
     // persistent waves per CU of both persistent kernels at this scene's LDS need (window + one spare row)
     {
         const size_t lds = (size_t)(std::min(ctx->stack_need, ctx->lds_window) + 1) * 64 * 4;
-        HIP_TRY(ctx, ptk_wavefront_occupancy(lds, &ctx->wf_waves_per_cu));
+        HIP_TRY(ctx, ptk_wavefront_occupancy((size_t)ctx->n_top * PTK_TOP_BLOCK_STRIDE + PTK_WF_WG_WAVES * lds, &ctx->wf_wgs_per_cu));
         HIP_TRY(ctx, ptk_persistent_occupancy(lds, &ctx->pp_waves_per_cu));
-        if (ctx->waves_per_cu_cap > 0) {
-            ctx->wf_waves_per_cu = std::min(ctx->wf_waves_per_cu, ctx->waves_per_cu_cap);
-            ctx->pp_waves_per_cu = std::min(ctx->pp_waves_per_cu, ctx->waves_per_cu_cap);
-        }
+        if (ctx->waves_per_cu_cap > 0) ctx->pp_waves_per_cu = std::min(ctx->pp_waves_per_cu, ctx->waves_per_cu_cap);
     }
     ctx->dirty = false;
     ctx->full_validations++;
@@ -810,6 +878,9 @@ static void fill_blocks(const ptk_ctx* ctx, PtkParams& P) {
     P.wf.root_min_x = ctx->root_box[0]; P.wf.root_min_y = ctx->root_box[1]; P.wf.root_min_z = ctx->root_box[2];
     P.wf.root_max_x = ctx->root_box[3]; P.wf.root_max_y = ctx->root_box[4]; P.wf.root_max_z = ctx->root_box[5];
     P.wf.root_entry = ctx->root_entry;
+    P.wf.n_top = ctx->n_top;
+    P.wf.n_chain = ctx->n_chain;
+    memcpy(P.wf.chain, ctx->chain, sizeof P.wf.chain);
     P.wf.n_blocks = ctx->n_blocks; P.wf.n_sockets = ctx->n_sockets; P.wf.n_records = ctx->n_records;
     P.wf.leaf_records = ctx->d_leaf_records;
 }
@@ -1006,14 +1077,15 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         P.wf.n_slots = (uint32_t)n_slots;
         P.wf.tiles_x = groups_x;
     }
-    // persistent traversal waves: as many as fit on the device at once
-    const size_t wf_lds = (size_t)(P.lds_cap + 1) * 64 * 4;  // one spare row for rejected children
-    const int waves_per_cu = ctx->wf_waves_per_cu;
-    if (waves_per_cu <= 0) return fail(ctx, PTK_E_HIP, "the traversal kernel does not fit on a compute unit");
-    const int n_waves = (int)std::min<size_t>((size_t)waves_per_cu * std::max(ctx->n_cus, 1), (n_slots + 63) / 64);
+    // persistent traversal workgroups: as many as fit on the device at once
+    const size_t wf_lds = (size_t)ctx->n_top * PTK_TOP_BLOCK_STRIDE + (size_t)PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64 * 4;  // one spare row per wave
+    if (ctx->wf_wgs_per_cu <= 0) return fail(ctx, PTK_E_HIP, "the traversal kernel does not fit on a compute unit");
+    const size_t wg_rays = (size_t)PTK_WF_WG_WAVES * 64;
+    const int n_wgs = (int)std::min<size_t>((size_t)ctx->wf_wgs_per_cu * std::max(ctx->n_cus, 1), (n_slots + wg_rays - 1) / wg_rays);
+    const size_t n_waves = (size_t)n_wgs * PTK_WF_WG_WAVES;
     P.spill = nullptr;
     P.spill_t = nullptr;
-    P.spill_stride = (size_t)n_waves * 64;
+    P.spill_stride = n_waves * 64;
     if (spill_entries > 0) {
         size_t ints = (size_t)spill_entries * n_waves * 64;
         if (ints > ctx->wf_spill_ints) {
@@ -1030,7 +1102,7 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     }
     ctx->wf_iters[slot] = n_iter;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
-    HIP_TRY(ctx, ptk_launch_wavefront(&P, groups_x, groups_y, n_iter, wf_lds, n_waves, ctx->wf_ev[slot], ctx->stream));
+    HIP_TRY(ctx, ptk_launch_wavefront(&P, groups_x, groups_y, n_iter, wf_lds, n_wgs, ctx->wf_ev[slot], ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
     ctx->dispatch_count++;
     return PTK_OK;
@@ -1087,6 +1159,17 @@ int ptk_dispatch_noalloc(ptk_ctx* ctx, const void* push128, int groups_x, int gr
     ctx->dispatch_count++;
     return PTK_OK;
 }
+
+#ifdef PTK_WF_STATS
+// Measurement builds only (not declared in ptk.h): reads and clears the traversal kernel's round statistics.
+extern "C" hipError_t ptk_wf_stats_fetch(unsigned long long* out, int n, hipStream_t stream);
+int ptk_dev_wf_stats(ptk_ctx* ctx, unsigned long long* out, int n) {
+    if (!ctx || !out) return PTK_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, ptk_wf_stats_fetch(out, n, ctx->stream));
+    return PTK_OK;
+}
+#endif
 
 int ptk_update_stats(ptk_ctx* ctx, long long* full_validations, long long* patched_updates) {
     if (!ctx || !full_validations || !patched_updates) return PTK_E_INVALID;

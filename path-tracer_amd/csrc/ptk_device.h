@@ -40,6 +40,17 @@ struct PtkTexDesc {
 // in a parallel array that only the shading kernel touches; the hit record of
 // entry i is hits[i] = {hit, object_id, transform_index, bits(t)} and hit_uv[i].
 #define PTK_WF_MAX_ITER 32
+// The top of many trees is a chain every ray walks in the same way: a root with one child, a mesh socket, a
+// mesh root with one child (scene root -> PTMesh socket -> mesh tree is the plugin's usual layout).  Those
+// steps need no per-lane node fetch: the host lists them here (they travel as kernel arguments) and every
+// search runs them before its first fetched node.  A step is one box test (the only child of a one-child
+// inner node) or the entry into a mesh socket.
+#define PTK_MAX_CHAIN 6
+struct PtkChainStep {
+    float lo[3], hi[3];   // kind 0: the child's box (min - pad, max + pad as stored in the node buffer)
+    int32_t kind;         // 0 box test, 1 mesh socket
+    int32_t xf;           // kind 1: transform index
+};
 struct PtkWavefront {
     float4* rays[2];
     int4* hits;
@@ -60,7 +71,11 @@ struct PtkWavefront {
     const float4* blocks;
     const int2* sockets;     // per world-level mesh socket: {entry of the mesh's root, transform index}
     float root_min_x, root_min_y, root_min_z, root_max_x, root_max_y, root_max_z;  // box of the root node
-    uint32_t root_entry;
+    uint32_t root_entry;       // what a search visits first once the root box and the chain below are passed
+    int32_t n_chain;
+    PtkChainStep chain[PTK_MAX_CHAIN];
+    uint32_t n_top;            // blocks [0, n_top) are the top of the tree in breadth-first order: the traversal
+                               // kernel keeps a copy of them in LDS (272-byte stride) and reads them there
     uint32_t n_blocks, n_sockets, n_records;  // array lengths (checked builds)
     const float4* leaf_records;  // 3 float4 per object-id slot: the primitive a leaf tests, by value
 };
@@ -96,10 +111,16 @@ struct PtkParams {
 extern "C" hipError_t ptk_launch_render(const PtkParams* p, int gx, int gy, int trace, int early_t,
                                         size_t lds_bytes, hipStream_t stream);
 // Wavefront renderer: generate, then n_iter x (traverse, shade).  ev[2k], ev[2k+1] (may be null) are
-// recorded around the k-th traversal launch.  n_waves = persistent traversal waves.
+// recorded around the k-th traversal launch.  n_wgs = persistent traversal workgroups (PTK_WF_WG_WAVES waves each),
+// lds_bytes = their dynamic LDS: n_top * PTK_TOP_BLOCK_STRIDE + PTK_WF_WG_WAVES * (lds_cap + 1) * 256.
 extern "C" hipError_t ptk_launch_wavefront(const PtkParams* p, int gx, int gy, int n_iter, size_t lds_bytes,
-                                           int n_waves, hipEvent_t* ev, hipStream_t stream);
-extern "C" hipError_t ptk_wavefront_occupancy(size_t lds_bytes, int* waves_per_cu);
+                                           int n_wgs, hipEvent_t* ev, hipStream_t stream);
+// Traversal workgroups are PTK_WF_WG_WAVES waves that share one LDS copy of the top blocks; *wgs_per_cu =
+// resident workgroups per compute unit at that LDS size.
+#define PTK_WF_WG_WAVES 16
+#define PTK_LDS_BYTES_PER_CU 163840
+#define PTK_TOP_BLOCK_STRIDE 272  /* bytes between top blocks in LDS: 256 + 16, so that lanes on different blocks spread over the banks */
+extern "C" hipError_t ptk_wavefront_occupancy(size_t lds_bytes, int* wgs_per_cu);
 extern "C" hipError_t ptk_launch_persistent(const PtkParams* p, size_t lds_bytes, int n_waves, hipStream_t stream);
 extern "C" hipError_t ptk_persistent_occupancy(size_t lds_bytes, int* waves_per_cu);
 // Static device scratch of ptk_dispatch_noalloc (a file-scope __device__ array in ptk_persistent.hip):

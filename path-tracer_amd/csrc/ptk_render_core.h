@@ -222,6 +222,8 @@ PTK_DEV void hit_object(const PtkParams& P, Lane& L, Ray& ray, Hit& h, int objec
 
 // ---- traversal stack ------------------------------------------------------------
 struct Stack {
+    const float4* top = nullptr;  // LDS copy of node blocks [0, n_top), PTK_TOP_BLOCK_STRIDE bytes apart (traversal kernel only)
+    uint32_t n_top = 0;
     int* lds;        // this wave's LDS window, [entry][lane]
     int* spill;      // global column of this lane, stride = spill_stride ints
     size_t spill_stride;
@@ -571,7 +573,47 @@ struct Trav {
 PTK_DEV bool trav_is_leaf(const Trav& T) { return T.cur != ENTRY_NONE && (int)T.cur <= 0; }
 PTK_DEV bool trav_is_inner(const Trav& T) { return T.cur != ENTRY_NONE && (int)T.cur > 0; }
 
-// planes first, outside the BVH (:1204; only records with a non-zero normal can hit), then the root box
+// Entry into a mesh socket at world level (:1286-1313): the ray is taken into the mesh's space.
+PTK_DEV void trav_enter_mesh(const PtkParams& P, Trav& T, int xf) {
+    const m44 M = load_xform(P, xf);
+    T.w_o = T.o; T.w_d = T.d; T.w_start = T.start;
+    const f3 unnorm = mul_mv(M, T.d, 0.0f);
+    T.dir_len = length3(unnorm);
+    const f3 no = mul_mv(M, T.o, 1.0f);
+    T.d = div3(unnorm, T.dir_len);
+    T.o = no;
+    T.end = T.end * T.dir_len;
+    T.start = T.start * T.dir_len;
+    T.inv = mk3(1.0f / T.d.x, 1.0f / T.d.y, 1.0f / T.d.z);
+    T.sub_base = T.sp;
+    T.cur_xf = xf;
+}
+
+// hit_AABB (:670-689) and the acceptance test of :1152 for the only child of a one-child node: the same
+// operations, in the same order, as one slot of the packed test in trav_inner.
+PTK_DEV bool trav_single_child_accepts(const Trav& T, const PtkChainStep& c) {
+    const f3 o = T.o, inv = T.inv;
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const bool range_ok = T.start == T.start && T.end == T.end;
+    const float t0x = (c.lo[0] - o.x) * inv.x, t1x = (c.hi[0] - o.x) * inv.x;
+    const float t0y = (c.lo[1] - o.y) * inv.y, t1y = (c.hi[1] - o.y) * inv.y;
+    const float t0z = (c.lo[2] - o.z) * inv.z, t1z = (c.hi[2] - o.z) * inv.z;
+    const float swx = t0x + t1x, sbx = swx - t1x, scx = swx - sbx;
+    const float swy = t0y + t1y, sby = swy - t1y, scy = swy - sby;
+    const float swz = t0z + t1z, sbz = swz - t1z, scz = swz - sbz;
+    float start = T.start, end = T.end;
+    start = __builtin_fmaxf(start, nx ? scx : t0x);
+    end = __builtin_fminf(end, nx ? sbx : t1x);
+    start = __builtin_fmaxf(start, ny ? scy : t0y);
+    end = __builtin_fminf(end, ny ? sby : t1y);
+    start = __builtin_fmaxf(start, nz ? scz : t0z);
+    end = __builtin_fminf(end, nz ? sbz : t1z);
+    return (end > start) && range_ok;
+}
+
+// planes first, outside the BVH (:1204; only records with a non-zero normal can hit), then the root box,
+// then the chain of one-child nodes and mesh sockets at the top of the tree (PtkWavefront::chain): the
+// same tests a search would make there node by node, from kernel arguments instead of fetched blocks.
 PTK_DEV void trav_begin(const PtkParams& P, Trav& T, const Ray& world_ray) {
     const PtkWavefront& W = P.wf;
     Ray r = world_ray;
@@ -583,11 +625,25 @@ PTK_DEV void trav_begin(const PtkParams& P, Trav& T, const Ray& world_ray) {
     const float4 rmin = make_float4(W.root_min_x, W.root_min_y, W.root_min_z, 0.0f);
     const float4 rmax = make_float4(W.root_max_x, W.root_max_y, W.root_max_z, 0.0f);
     const float root_hit = hit_aabb_bl(rmin, rmax, T.o, T.inv, neg, T.start, T.end);
-    T.cur = in_range(root_hit, T.start, T.end) ? W.root_entry : ENTRY_NONE;
+    bool alive = in_range(root_hit, T.start, T.end);
     T.sp = 0;
     T.sub_base = 0;
     T.cur_xf = -1;
     T.dir_len = 1.0f;
+    for (int s = 0; s < W.n_chain; s++) {  // (uniform over the wave: the steps are kernel arguments)
+        const PtkChainStep& c = W.chain[s];
+        if (c.kind == 1) { if (alive) trav_enter_mesh(P, T, c.xf); }
+        else if (alive) alive = trav_single_child_accepts(T, c);
+    }
+    T.cur = alive ? W.root_entry : ENTRY_NONE;
+    if (!alive && T.cur_xf >= 0) {
+        // rejected inside the mesh: its empty sub-stack maps the ray back to world space (:1309-1310)
+        const float local_end = T.end;
+        T.o = T.w_o; T.d = T.w_d; T.start = T.w_start;
+        T.end = local_end / T.dir_len;
+        T.inv = mk3(1.0f / T.d.x, 1.0f / T.d.y, 1.0f / T.d.z);
+        T.cur_xf = -1;
+    }
 }
 
 // One inner step of a lane whose T.cur is an inner entry: enter a mesh socket, or slab-test the node's
@@ -600,19 +656,7 @@ PTK_DEV bool trav_inner(const PtkParams& P, const Stack& S, Trav& T) {
     if ((cur & 0xFF000000u) == SOCKET_MARK) {
         // world level: enter the mesh (:1286-1313); its root is the next node
         const int2 sock = W.sockets[cur & 0x00FFFFFFu];
-        const int xf = sock.y;
-        const m44 M = load_xform(P, xf);
-        T.w_o = T.o; T.w_d = T.d; T.w_start = T.start;
-        const f3 unnorm = mul_mv(M, T.d, 0.0f);
-        T.dir_len = length3(unnorm);
-        const f3 no = mul_mv(M, T.o, 1.0f);
-        T.d = div3(unnorm, T.dir_len);
-        T.o = no;
-        T.end = T.end * T.dir_len;
-        T.start = T.start * T.dir_len;
-        T.inv = mk3(1.0f / T.d.x, 1.0f / T.d.y, 1.0f / T.d.z);
-        T.sub_base = T.sp;
-        T.cur_xf = xf;
+        trav_enter_mesh(P, T, sock.y);
         T.cur = (uint32_t)sock.x;
         return false;
     }
@@ -621,10 +665,18 @@ PTK_DEV bool trav_inner(const PtkParams& P, const Stack& S, Trav& T) {
     const int node_size = (int)(cur >> 24);
     // the node's block: eight child slots as planes (minx[8] .. maxz[8], entry[8]), all fetched before
     // any is used; slots past node_size hold zeros and are ignored
-    const float4* __restrict__ cb = W.blocks + (size_t)(cur & 0x00FFFFFFu) * 16;
+    const uint32_t blk = cur & 0x00FFFFFFu;
     float4 q[14];
+    if (blk < S.n_top) {
+        // the top of the tree is resident in LDS: no trip through the vector cache for these
+        const float4* lb = S.top + (size_t)blk * (PTK_TOP_BLOCK_STRIDE / 16);
 #pragma unroll
-    for (int k = 0; k < 14; k++) q[k] = cb[k];
+        for (int k = 0; k < 14; k++) q[k] = lb[k];
+    } else {
+        const float4* __restrict__ cb = W.blocks + (size_t)blk * 16;
+#pragma unroll
+        for (int k = 0; k < 14; k++) q[k] = cb[k];
+    }
     __builtin_amdgcn_sched_barrier(0);
     const f3 o = T.o, inv = T.inv;
     const float rstart = T.start, rend = T.end;

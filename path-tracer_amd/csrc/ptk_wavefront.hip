@@ -16,6 +16,7 @@
 // traversal kernel never wait for the longest path of their tile, and shading runs on compacted rays.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "ptk_render_core.h"
 
@@ -42,6 +43,58 @@ PTK_DEV int lane_rank_in(unsigned long long mask) {  // set bits of mask below t
 
 }  // namespace
 
+#ifdef PTK_WF_STATS
+// Measurement build: per inner round of the traversal kernel, how many lanes run it, how many distinct
+// node blocks they fetch, how large the groups of lanes on one block are, and at which tree depth.
+//   [0, 65)    inner rounds by number of lanes on an inner node (sockets excluded)
+//   [65, 130)  inner rounds by number of distinct blocks among those lanes
+//   [130, 195) lane visits by size of the group of lanes that share the block
+//   [200, 232) lane visits by block depth          [232, 264) distinct block fetches by block depth
+//   [264]      lane visits of mesh sockets         [265] leaf rounds   [266] lanes on a leaf in leaf rounds
+#define PTK_WF_NSTATS 272
+__device__ unsigned long long g_wf_stats[PTK_WF_NSTATS];
+namespace {
+PTK_DEV void wf_stats_inner_round(const PtkParams& P, const Trav& T, bool is_inner, unsigned long long mi, int lane) {
+    const bool blk = is_inner && (T.cur & 0xFF000000u) != SOCKET_MARK;
+    const unsigned long long m = __ballot(blk);
+    int depth = 0;
+    if (blk) depth = (int)fbits(P.wf.blocks[(size_t)(T.cur & 0x00FFFFFFu) * 16 + 14].x);
+    depth = depth < 0 ? 0 : (depth > 31 ? 31 : depth);
+    int distinct = 0;
+    unsigned long long rest = m;
+    while (rest) {
+        const int leader = __builtin_ctzll(rest);
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)T.cur, leader);
+        const int d = __builtin_amdgcn_readlane(depth, leader);
+        const unsigned long long same = __ballot(blk && T.cur == v);
+        const int g = __popcll(same);
+        rest &= ~same;
+        distinct++;
+        if (lane == 0) {
+            atomicAdd(&g_wf_stats[130 + g], (unsigned long long)g);
+            atomicAdd(&g_wf_stats[200 + d], (unsigned long long)g);
+            atomicAdd(&g_wf_stats[232 + d], 1ull);
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&g_wf_stats[__popcll(m)], 1ull);
+        atomicAdd(&g_wf_stats[65 + distinct], 1ull);
+        atomicAdd(&g_wf_stats[264], (unsigned long long)(__popcll(mi) - __popcll(m)));
+    }
+}
+}  // namespace
+extern "C" hipError_t ptk_wf_stats_fetch(unsigned long long* out, int n, hipStream_t stream) {
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    unsigned long long h[PTK_WF_NSTATS];
+    e = hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wf_stats), sizeof h);
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < n && i < PTK_WF_NSTATS; i++) out[i] = h[i];
+    memset(h, 0, sizeof h);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wf_stats), h, sizeof h);
+}
+#endif
+
 __global__ __launch_bounds__(64) void ptk_wf_generate(const PtkParams P) {
     const PtkWavefront& W = P.wf;
     const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
@@ -58,13 +111,27 @@ __global__ __launch_bounds__(64) void ptk_wf_generate(const PtkParams P) {
 // Closest hit of every ray of bounce `iter`.  Per lane this is the block traversal of
 // ptk_render_core.h (trav_*: the reference's order of box and object tests); around it, lanes whose ray
 // is finished write the hit record and claim the next queue entry.
-__global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int iter) {
-    extern __shared__ int lds_stack[];  // [entry][lane], P.lds_cap rows + one spare row
-    const int lane = threadIdx.x;
+//
+// A workgroup is PTK_WF_WG_WAVES independent waves that share one thing: an LDS copy of the top of the
+// block tree (blocks [0, n_top), breadth-first from the root), loaded once per launch.  About half of all
+// node visits are to those few blocks; reading them from LDS takes them off the vector cache's gather path,
+// which handles one lane's address per clock and is what this kernel saturates otherwise.
+__global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const PtkParams P, int iter) {
+    // [top blocks: n_top * 272 bytes][per wave: stack window [entry][lane], P.lds_cap rows + one spare row]
+    extern __shared__ __attribute__((aligned(16))) int lds_all[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const PtkWavefront& W = P.wf;
+    {
+        float4* top = (float4*)lds_all;
+        for (uint32_t i = threadIdx.x; i < W.n_top * 16u; i += PTK_WF_WG_WAVES * 64)
+            top[(i >> 4) * (PTK_TOP_BLOCK_STRIDE / 16) + (i & 15u)] = W.blocks[i];
+        __syncthreads();  // the only workgroup-wide step: from here on every wave runs on its own
+    }
     Stack S;
-    S.lds = lds_stack; S.lane = lane; S.lds_cap = P.lds_cap; S.spill_stride = P.spill_stride;
-    S.spill = P.spill ? P.spill + (size_t)blockIdx.x * 64 + lane : nullptr;
+    S.top = (const float4*)lds_all; S.n_top = W.n_top;
+    S.lds = lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + wave * (P.lds_cap + 1) * 64;
+    S.lane = lane; S.lds_cap = P.lds_cap; S.spill_stride = P.spill_stride;
+    S.spill = P.spill ? P.spill + ((size_t)blockIdx.x * PTK_WF_WG_WAVES + wave) * 64 + lane : nullptr;
 
     const uint32_t count = __builtin_amdgcn_readfirstlane(W.counts[iter]);
     const float4* __restrict__ rq = W.rays[iter & 1];
@@ -88,6 +155,9 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
 
         if ((mi | ml) == 0ull || (!exhausted && n_idle >= PTK_WF_REFILL)) {
             // ---- refill round: retire finished rays, claim new ones ----
+#ifdef PTK_WF_STATS
+            if (lane == 0) atomicAdd(&g_wf_stats[271], 1ull);
+#endif
             if (have && T.cur == ENTRY_NONE) {
                 W.hits[ray_idx] = make_int4(T.h.hit, T.h.object_id, T.h.transform_index, (int)fbits(T.end));
                 W.hit_uv[ray_idx] = make_float2(T.h.u, T.h.v);
@@ -126,6 +196,15 @@ __global__ __launch_bounds__(64) void ptk_wf_traverse(const PtkParams P, int ite
         }
 
         bool pop = false;
+#ifdef PTK_WF_STATS
+        if (PTK_WF_VOTE_INNER(__popcll(mi), __popcll(ml))) {
+            wf_stats_inner_round(P, T, is_inner, mi, lane);
+            if (lane == 0) { atomicAdd(&g_wf_stats[267], (unsigned long long)__popcll(ml)); atomicAdd(&g_wf_stats[268], (unsigned long long)n_idle); }
+        } else if (lane == 0) {
+            atomicAdd(&g_wf_stats[265], 1ull); atomicAdd(&g_wf_stats[266], (unsigned long long)__popcll(ml));
+            atomicAdd(&g_wf_stats[269], (unsigned long long)__popcll(mi)); atomicAdd(&g_wf_stats[270], (unsigned long long)n_idle);
+        }
+#endif
         if (PTK_WF_VOTE_INNER(__popcll(mi), __popcll(ml))) {
             if (is_inner) pop = trav_inner(P, S, T);  // ---- inner round ----
         } else {
@@ -257,23 +336,26 @@ __global__ __launch_bounds__(SHADE_BLOCK) void ptk_wf_shade(const PtkParams P, i
                                             bitsf((uint32_t)((L.refraction_bounces & 0x3FFFFFFF) | (store_inside ? (1 << 30) : 0))));
 }
 
-extern "C" hipError_t ptk_wavefront_occupancy(size_t lds_bytes, int* waves_per_cu) {
+extern "C" hipError_t ptk_wavefront_occupancy(size_t lds_bytes, int* wgs_per_cu) {
     int n = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ptk_wf_traverse, 64, lds_bytes);
+    // a workgroup may use up to the whole 160 KiB of a compute unit
+    hipError_t e = hipFuncSetAttribute((const void*)ptk_wf_traverse, hipFuncAttributeMaxDynamicSharedMemorySize, PTK_LDS_BYTES_PER_CU);
     if (e != hipSuccess) return e;
-    *waves_per_cu = n;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ptk_wf_traverse, PTK_WF_WG_WAVES * 64, lds_bytes);
+    if (e != hipSuccess) return e;
+    *wgs_per_cu = n;
     return hipSuccess;
 }
 
 extern "C" hipError_t ptk_launch_wavefront(const PtkParams* p, int gx, int gy, int n_iter, size_t lds_bytes,
-                                           int n_waves, hipEvent_t* ev, hipStream_t stream) {
+                                           int n_wgs, hipEvent_t* ev, hipStream_t stream) {
     const unsigned blocks = (unsigned)gx * (unsigned)gy;
     hipError_t e = hipMemsetAsync(p->wf.counts, 0, 1024, stream);  // counts, heads (and development counters)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ptk_wf_generate, dim3(blocks), dim3(64), 0, stream, *p);
     for (int it = 0; it < n_iter; it++) {
         if (ev) { e = hipEventRecord(ev[2 * it], stream); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL(ptk_wf_traverse, dim3((unsigned)n_waves), dim3(64), lds_bytes, stream, *p, it);
+        hipLaunchKernelGGL(ptk_wf_traverse, dim3((unsigned)n_wgs), dim3(PTK_WF_WG_WAVES * 64), lds_bytes, stream, *p, it);
         if (ev) { e = hipEventRecord(ev[2 * it + 1], stream); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL(ptk_wf_shade, dim3((blocks * 64u + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, stream, *p, it);
     }

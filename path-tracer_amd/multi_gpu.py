@@ -8,10 +8,12 @@ pt_render_window.gd:179-189), and a seed that depends only on the absolute pixel
 * tiles   -- every rank renders a band of 8-pixel tile rows of every sample; bands are disjoint, so the
              assembled image is bit-identical to a one-GPU render and the only exchange is a gather of
              bands when the image is wanted.
-* samples -- every rank renders the whole frame for its own batch of samples and keeps its own running
-             mean; the means are averaged with one reduce per batch.  (The running mix of
-             ray_tracer.comp:1693-1697 over frames 0..K-1 equals the arithmetic mean of samples 1..K-1,
-             so the average of per-rank means is the mean over all samples up to rounding.)
+* samples -- every rank renders the whole frame for its own batch of K samples and keeps its own running
+             mean; the means are averaged with one reduce per batch.  The running mix of
+             ray_tracer.comp:1693-1697 weights a sample by 1 / max(1, frame), so frames 0 and 1 both
+             overwrite: a batch numbered 0..K-1 would throw its first sample away on every rank.  A
+             batch is therefore numbered 1..K (batch_frame): the mix then is the arithmetic mean of all K
+             samples, and the average over N ranks is the mean of all N*K samples up to rounding.
 
 The functions here work on torch tensors of any device, so the same code runs over RCCL on GPUs and
 over gloo in the CPU tests.
@@ -28,6 +30,12 @@ import torch.distributed as dist
 def sample_index(rank: int, steps_per_rank: int, k: int) -> int:
     """Global index of the k-th sample of `rank`'s batch: batches are consecutive and disjoint."""
     return rank * steps_per_rank + k
+
+
+def batch_frame(k: int) -> int:
+    """The `frame` push constant of the k-th sample of a rank's batch: numbering starts at 1, where the
+    running mix keeps every sample (frame 0 would be overwritten by frame 1)."""
+    return k + 1
 
 
 def row_bands(groups_y: int, world: int) -> List[Tuple[int, int]]:

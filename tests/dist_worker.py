@@ -25,12 +25,12 @@ def _setup():
     return ob, pta, wd, scene, packed
 
 
-def render_samples(ob, wd, scene, packed, sample_ids, window=None):
-    """Progressive render of the given global sample indices (frame = position in the batch)."""
+def render_samples(ob, wd, scene, packed, sample_ids, window=None, first_frame=0):
+    """Progressive render of the given global sample indices (frame = first_frame + position in the batch)."""
     img = np.zeros((H, W, 4), np.float32)
-    for frame, k in enumerate(sample_ids):
+    for pos, k in enumerate(sample_ids):
         win = window or wd.PTRenderWindow(render_width=W, render_height=H, max_ray_depth=DEPTH)
-        win.frame = frame
+        win.frame = first_frame + pos
         ob.render(packed, wd.push_constant_bytes(scene.camera, win, wd.sample_time(k)), img,
                   win.work_group_width, win.work_group_height, nthreads=1)
     return img
@@ -46,7 +46,7 @@ def worker(rank, world, port, out_dir):
         ob, pta, wd, scene, packed = _setup()
         # partitioning by sample batches: every rank renders its own samples, one reduce at the end
         mine = [mg.sample_index(rank, STEPS, k) for k in range(STEPS)]
-        acc = torch.from_numpy(render_samples(ob, wd, scene, packed, mine))
+        acc = torch.from_numpy(render_samples(ob, wd, scene, packed, mine, first_frame=mg.batch_frame(0)))
         mg.reduce_batch_means(acc, dst=0)
         # partitioning by tile rows: every rank renders its band of one sample, one gather at the end
         base = wd.PTRenderWindow(render_width=W, render_height=H, max_ray_depth=DEPTH)

@@ -138,7 +138,8 @@ def test_row_bands_cover_the_image():
 
 def test_two_rank_partitioning_matches_one_rank(tmp_path):
     """World size 2 over gloo: tile rows assemble to the one-rank image bit for bit; sample batches
-    average to the mean of the same samples (summation order differs: tolerance 1e-6 absolute)."""
+    (numbered from frame 1) average to the mean of all samples of all ranks (summation order differs from a
+    sequential mix: tolerance 1e-6 absolute)."""
     import torch.multiprocessing as mp
 
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -154,7 +155,24 @@ def test_two_rank_partitioning_matches_one_rank(tmp_path):
     whole = dw.render_samples(ob, wd, scene, packed, [1])
     tiles = np.load(tmp_path / "tiles.npy")
     assert np.array_equal(tiles.view(np.uint32), whole.view(np.uint32))
-    means = [dw.render_samples(ob, wd, scene, packed, [r * dw.STEPS + k for k in range(dw.STEPS)]) for r in range(2)]
-    expect = (means[0].astype(np.float64) + means[1].astype(np.float64)) / 2
+    # no sample is thrown away: the combined image is the plain mean of all 2 * STEPS samples, each rendered alone
+    singles = [dw.render_samples(ob, wd, scene, packed, [k]).astype(np.float64) for k in range(2 * dw.STEPS)]
+    expect = sum(singles) / len(singles)
     got = np.load(tmp_path / "batch_mean.npy")
     assert np.abs(got - expect).max() <= 1e-6
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` outside a launcher starts torch.distributed.run itself (one rank per GPU,
+    rendezvous on 127.0.0.1) before importing anything that touches a GPU; here only the command is printed."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PTK_BENCH_PRINT_LAUNCH"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
