@@ -81,6 +81,15 @@ int ptk_buffer_read(ptk_ctx* ctx, uint64_t buffer, size_t offset, void* dst, siz
 uint64_t ptk_image_create(ptk_ctx* ctx, int width, int height);
 /* Replaces rd.texture_get_data(image, 0), pt_renderer.gd:327: width*height*16 bytes. */
 int ptk_image_read(ptk_ctx* ctx, uint64_t image, void* dst, size_t nbytes);
+/* The display side of the image (shaders/canvas.gdshader:22-36, shown through the Texture2DRD of
+ * pt_work_dispatcher.gd:192-196 and pt_renderer.gd:519-540): width*height*4 bytes of RGBA8, ready for a Godot
+ * ImageTexture, converted on the GPU so that a quarter of the bytes cross PCIe.  transfer selects how much of
+ * the canvas shader's work is done here: PTK_DISPLAY_STORED = clamp and quantise the stored values (the canvas
+ * shader then applies its own pow when it samples; also what a screenshot of the floats clamps to,
+ * pt_renderer.gd:320-350); PTK_DISPLAY_CANVAS = the shader's pow(rgb, 2.2) first (canvas.gdshader:33);
+ * PTK_DISPLAY_CANVAS_SRGB = that, then the linear -> sRGB encoding of Godot's viewport output. */
+enum { PTK_DISPLAY_STORED = 0, PTK_DISPLAY_CANVAS = 1, PTK_DISPLAY_CANVAS_SRGB = 2 };
+int ptk_image_read_display(ptk_ctx* ctx, uint64_t image, void* dst_rgba8, size_t nbytes, int transfer);
 /* Replaces rd.texture_update on the image (created with CAN_UPDATE, pt_work_dispatcher.gd:375-382). */
 int ptk_image_update(ptk_ctx* ctx, uint64_t image, const void* src, size_t nbytes);
 

@@ -96,6 +96,8 @@ struct ptk_ctx {
     size_t wf_slots = 0;
     int* d_wf_spill = nullptr;
     uint32_t* d_pixel_counter = nullptr;  // persistent renderer: next pixel slot to hand out
+    void* d_display = nullptr;     // RGBA8 staging of ptk_image_read_display
+    size_t display_bytes = 0;
     size_t wf_spill_ints = 0;
     int n_cus = 0;
     int lds_window = 32;           // traversal stack entries per lane kept in LDS (PTK_LDS_WINDOW, read once at create)
@@ -209,6 +211,7 @@ void ptk_destroy(ptk_ctx* ctx) {
     if (ctx->d_wf) (void)hipFree(ctx->d_wf);
     if (ctx->d_wf_spill) (void)hipFree(ctx->d_wf_spill);
     if (ctx->d_pixel_counter) (void)hipFree(ctx->d_pixel_counter);
+    if (ctx->d_display) (void)hipFree(ctx->d_display);
     for (int i = 0; i < ptk_ctx::kTimingRing; i++) {
         if (ctx->wf_ev[i]) {
             for (int k = 0; k < 2 * PTK_WF_MAX_ITER; k++) (void)hipEventDestroy(ctx->wf_ev[i][k]);
@@ -338,6 +341,27 @@ int ptk_image_read(ptk_ctx* ctx, uint64_t image, void* dst, size_t nbytes) {
     if (!dst || nbytes != o->nbytes) return fail(ctx, PTK_E_INVALID, "image read needs exactly %zu bytes", o->nbytes);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(dst, o->dev, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTK_OK;
+}
+
+int ptk_image_read_display(ptk_ctx* ctx, uint64_t image, void* dst_rgba8, size_t nbytes, int transfer) {
+    if (!ctx) return PTK_E_INVALID;
+    Object* o = find(ctx, image, Kind::Image);
+    if (!o) return fail(ctx, PTK_E_INVALID, "unknown image handle");
+    const size_t n_pixels = (size_t)o->width * o->height;
+    if (!dst_rgba8 || nbytes != n_pixels * 4) return fail(ctx, PTK_E_INVALID, "display read needs exactly %zu bytes", n_pixels * 4);
+    if (transfer < PTK_DISPLAY_STORED || transfer > PTK_DISPLAY_CANVAS_SRGB) return fail(ctx, PTK_E_INVALID, "unknown display transfer %d", transfer);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t need = (nbytes + 255) & ~(size_t)255;
+    if (need > ctx->display_bytes) {
+        if (ctx->d_display) { (void)hipFree(ctx->d_display); ctx->d_display = nullptr; }
+        ctx->display_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_display, need));
+        ctx->display_bytes = need;
+    }
+    HIP_TRY(ctx, ptk_launch_display((const float4*)o->dev, ctx->d_display, n_pixels, transfer, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dst_rgba8, ctx->d_display, nbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PTK_OK;
 }

@@ -128,3 +128,5 @@ extern "C" hipError_t ptk_persistent_occupancy(size_t lds_bytes, int* waves_per_
 #define PTK_NOALLOC_SCRATCH_BYTES ((size_t)8 << 20)
 extern "C" hipError_t ptk_persistent_scratch_init(int device);
 extern "C" void* ptk_persistent_scratch(int device);
+// Display conversion (ptk_display.hip): rgba32f image -> RGBA8, n_pixels * 4 bytes at out_rgba8 (device, 16-byte aligned).
+extern "C" hipError_t ptk_launch_display(const float4* image, void* out_rgba8, size_t n_pixels, int transfer, hipStream_t stream);

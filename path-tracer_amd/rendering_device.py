@@ -30,6 +30,7 @@ EXPORTS = [
     "ptk_dispatch", "ptk_sync", "ptk_free", "ptk_bvh_build", "ptk_bvh_sizes", "ptk_bvh_read",
     "ptk_trace_enable", "ptk_trace_read", "ptk_last_dispatch_ms", "ptk_dispatch_history_ms", "ptk_image_copy_device",
     "ptk_set_renderer", "ptk_dispatch_traverse_ms", "ptk_update_stats", "ptk_dispatch_noalloc",
+    "ptk_image_read_display",
 ]
 
 PTK_RENDERER_AUTO, PTK_RENDERER_SINGLE_KERNEL, PTK_RENDERER_WAVEFRONT, PTK_RENDERER_PERSISTENT = 0, 1, 2, 3
@@ -68,6 +69,8 @@ def load_library() -> C.CDLL:
     lib.ptk_image_create.argtypes = [vp, C.c_int, C.c_int]
     lib.ptk_image_read.restype = C.c_int
     lib.ptk_image_read.argtypes = [vp, u64, vp, C.c_size_t]
+    lib.ptk_image_read_display.restype = C.c_int
+    lib.ptk_image_read_display.argtypes = [vp, u64, vp, C.c_size_t, C.c_int]
     lib.ptk_image_update.restype = C.c_int
     lib.ptk_image_update.argtypes = [vp, u64, vp, C.c_size_t]
     lib.ptk_texture_create.restype = u64
@@ -178,6 +181,13 @@ class PtkRenderingDevice:
         w, h = self._images[image]
         out = np.empty((h, w, 4), dtype=np.float32)
         self._check(self.lib.ptk_image_read(self.ctx, image, out.ctypes.data, out.nbytes), "ptk_image_read")
+        return out
+
+    def texture_get_display(self, image: int, transfer: int = 1) -> np.ndarray:
+        """RGBA8 of the image as the canvas shows it (0 stored values, 1 canvas.gdshader's pow 2.2, 2 that + sRGB)."""
+        w, h = self._images[image]
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        self._check(self.lib.ptk_image_read_display(self.ctx, image, out.ctypes.data, out.nbytes, transfer), "ptk_image_read_display")
         return out
 
     def texture_update(self, image: int, data: np.ndarray):

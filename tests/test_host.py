@@ -176,3 +176,20 @@ def test_bench_launches_its_own_ranks():
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+
+
+def test_header_is_plain_c_and_harness_fails_loudly_without_gpu(tmp_path):
+    """include/ptk.h compiles as C99 with -pedantic-errors; the C harness, run where no GPU exists, reports
+    ptk_create's error and exits non-zero instead of rendering anywhere else."""
+    src = tmp_path / "t.c"
+    src.write_text('#include "ptk.h"\nint main(void) { ptk_ctx* c = ptk_create(0); ptk_destroy(c); return PTK_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic-errors", "-Wall", "-Werror", "-fsyntax-only",
+                           "-I", os.path.join(ROOT, "include"), str(src)])
+    harness = os.path.join(ROOT, "tests", "c_abi", "c_abi_harness")
+    if not os.path.exists(harness):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(harness)])
+    out = subprocess.run([harness, os.path.join(ROOT, "tests", "golden", "c_harness_sphere_scene1.bin"),
+                          str(tmp_path / "a"), str(tmp_path / "b")], capture_output=True, text=True, timeout=120)
+    if out.returncode == 0:
+        pytest.skip("a GPU is present")
+    assert "ptk_create" in out.stderr and "device" in out.stderr.lower(), out.stderr
