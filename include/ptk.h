@@ -144,6 +144,40 @@ int ptk_bvh_sizes(ptk_ctx* ctx, uint64_t bvh, int32_t* n_nodes, int32_t* n_objec
  * 32 bytes per node in index_tree order, and the object id table. */
 int ptk_bvh_read(ptk_ctx* ctx, uint64_t bvh, void* node_bytes, int32_t* object_ids);
 
+/* Replaces PTObjectContainer.mesh_to_pttriangles (proprietary_dataclasses/pt_object_container.gd:163-186: one
+ * PTTriangle per index triplet of Mesh.surface_get_arrays(0)) together with what those triangles feed:
+ * PTTriangle.to_byte_array (public/primitives/pt_triangle.gd:125-150) and get_bvh_aabb (pt_triangle.gd:107-112,
+ * pt_object.gd:269-272).  The surface is given as Godot stores it (the dictionary of
+ * RenderingServer.mesh_get_surface: format flags, vertex / attribute / index byte blocks, aabb, uv_scale);
+ * positions are float32 or, under ARRAY_FLAG_COMPRESS_ATTRIBUTES, unorm16 relative to the aabb.  Surfaces without
+ * an index array or with custom attribute channels are PTK_E_UNSUPPORTED.
+ *   transform12    the meshlets' Transform3D as basis rows (9) + origin (3); NULL = identity, points copied as stored
+ *   records80      out, index_count / 3 records of 80 bytes, ready for the (2,3) triangle buffer
+ *   aabbs6         out or NULL, position.xyz,size.xyz per triangle in ptk_bvh_build's input form
+ *   uvs6           out or NULL, (u,v) of the three corners per triangle (zeros when the surface has no UVs):
+ *                  PTTriangle.set_uvs; the per-triangle table PTK_OPT_TRIANGLE_UVS reads at (4,1)
+ * Returns the triangle count in *n_triangles. */
+typedef struct ptk_mesh_surface {
+    uint64_t format;                 /* Mesh.ArrayFormat flags of the surface */
+    int32_t vertex_count, index_count;
+    const void* vertex_data; size_t vertex_bytes;
+    const void* attribute_data; size_t attribute_bytes;   /* may be NULL / 0 */
+    const void* index_data; size_t index_bytes;
+    float aabb[6];                   /* position.xyz, size.xyz */
+    float uv_scale[4];
+} ptk_mesh_surface;
+int ptk_mesh_to_triangles(ptk_ctx* ctx, const ptk_mesh_surface* surface, const float* transform12, int32_t material_index,
+                          uint32_t texture_id, void* records80, float* aabbs6, float* uvs6, int32_t* n_triangles);
+
+/* Switches with no counterpart in the reference; every one defaults to the reference's behaviour.
+ * PTK_OPT_TRIANGLE_UVS (default 0): with 1, the buffer at (4,1) -- bound but never read by the reference
+ * (ray_tracer.comp:396-406) -- is read as six floats per triangle record, the (u,v) of point1, point2, point3
+ * (ptk_mesh_to_triangles' uvs6), and a triangle hit's uv becomes their interpolation
+ * (1-u-v)*uv1 + u*uv2 + v*uv3 instead of the barycentric (u,v) themselves: the conversion the shader leaves as
+ * a TODO at ray_tracer.comp:1071-1072.  Triangles past the end of the table keep the barycentric uv. */
+enum { PTK_OPT_TRIANGLE_UVS = 1 };
+int ptk_set_option(ptk_ctx* ctx, int option, int value);
+
 /* Measurement hooks.  The reference counts box and object tests per invocation
  * in node_hit_count / object_hit_count (ray_tracer.comp:221-222,672,982) and
  * can only show them through the BVH-view render mode; these calls expose the

@@ -424,6 +424,13 @@ static void determine_rayhit(Ctx* c, const Ray* ray_in, RayHit* rh) { /* :1003-1
             rh->normal = v3_normalize(v_mul_m4(rh->normal, 0.0f, &m));
             rh->point = m4_mul_v(&matrix, rh->point, 1.0f);
         }
+        if (c->S->triangle_uvs && index >= 0 && index < c->S->n_triangle_uvs) {
+            /* uv.x*uv2 + uv.y*uv3 + (1 - uv.x - uv.y)*uv1, in the order of the point above */
+            const float* q = c->S->triangle_uvs + (size_t)index * 6;
+            float bu = rh->uv_x, bv = rh->uv_y;
+            rh->uv_x = (q[2] * bu + q[4] * bv) + q[0] * w;
+            rh->uv_y = (q[3] * bu + q[5] * bv) + q[1] * w;
+        }
         if (v3_dot(rh->normal, ray_in->direction) > 0.0f) rh->normal = v3_scale(rh->normal, -1.0f);
         c->st[PTO_ST_HIT_TRIANGLE]++;
     }

@@ -51,6 +51,10 @@ typedef struct {
     int early_t_break;    /* use_early_t_break */
     int n_proc;           /* number of spliced procedural functions */
     const int32_t* proc_builtin; /* function index i+1 -> PTO_PROC_* */
+    /* Extension beyond the reference (its TODO at ray_tracer.comp:1071-1072): when non-NULL, six floats per
+     * triangle record -- (u,v) of point1, point2, point3 -- and a triangle hit's uv becomes their barycentric
+     * interpolation instead of the barycentric coordinates themselves.  NULL = the reference's behaviour. */
+    const float* triangle_uvs; int n_triangle_uvs;
 } pto_scene;
 
 typedef struct {

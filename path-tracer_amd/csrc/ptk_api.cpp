@@ -52,6 +52,7 @@ struct ptk_ctx {
     std::map<int, uint64_t> texture_slots;
     // configuration (ptk_configure)
     int order = 8, refraction_mode = 2, use_emission = 0, early_t_break = 0;
+    int opt_triangle_uvs = 0;  // PTK_OPT_TRIANGLE_UVS
     int n_proc = 0;
     int proc_builtin[PTK_MAX_PROC] = {0};
     // derived state, rebuilt when a bound buffer changes
@@ -892,6 +893,12 @@ static int fill_params(ptk_ctx* ctx, const void* push128, PtkParams& P) {
     memcpy(P.proc_builtin, ctx->proc_builtin, sizeof P.proc_builtin);
     P.refraction_mode = ctx->refraction_mode;
     P.use_emission = ctx->use_emission;
+    if (ctx->opt_triangle_uvs) {
+        Object* uv = bound_buffer(ctx, PTK_SET_TRIANGLE, 1);
+        if (!uv) return fail(ctx, PTK_E_STATE, "PTK_OPT_TRIANGLE_UVS is on but no buffer is bound at (4,1)");
+        P.triangle_uvs = (const float*)uv->dev;
+        P.n_triangle_uvs = (int)(uv->nbytes / 24);  // triangles beyond the table keep their barycentric uv
+    }
     return PTK_OK;
 }
 
@@ -1202,6 +1209,12 @@ int ptk_update_stats(ptk_ctx* ctx, long long* full_validations, long long* patch
     return PTK_OK;
 }
 
+int ptk_set_option(ptk_ctx* ctx, int option, int value) {
+    if (!ctx) return PTK_E_INVALID;
+    if (option == PTK_OPT_TRIANGLE_UVS) { ctx->opt_triangle_uvs = value ? 1 : 0; return PTK_OK; }
+    return fail(ctx, PTK_E_INVALID, "unknown option %d", option);
+}
+
 int ptk_set_renderer(ptk_ctx* ctx, int renderer) {
     if (!ctx) return PTK_E_INVALID;
     if (renderer != PTK_RENDERER_AUTO && renderer != PTK_RENDERER_SINGLE_KERNEL && renderer != PTK_RENDERER_WAVEFRONT &&
@@ -1250,6 +1263,71 @@ int ptk_image_copy_device(ptk_ctx* ctx, uint64_t image, void* device_ptr, size_t
     if (to_image) HIP_TRY(ctx, hipMemcpyAsync(o->dev, device_ptr, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
     else HIP_TRY(ctx, hipMemcpyAsync(device_ptr, o->dev, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTK_OK;
+}
+
+// ---- mesh ingestion (device work in ptk_mesh.hip) ---------------------------------------------------
+int ptk_mesh_to_triangles(ptk_ctx* ctx, const ptk_mesh_surface* sf, const float* transform12, int32_t material_index,
+                          uint32_t texture_id, void* records80, float* aabbs6, float* uvs6, int32_t* n_triangles) {
+    if (!ctx) return PTK_E_INVALID;
+    if (!sf || !records80 || !n_triangles) return fail(ctx, PTK_E_INVALID, "surface, record buffer and count pointer are required");
+    // Mesh.ArrayFormat: VERTEX 1<<0, COLOR 1<<3, TEX_UV 1<<4, TEX_UV2 1<<5, CUSTOM0..3 1<<6..9, INDEX 1<<12,
+    // ARRAY_FLAG_COMPRESS_ATTRIBUTES 1<<29
+    const uint64_t f = sf->format;
+    if (!(f & 1ull)) return fail(ctx, PTK_E_UNSUPPORTED, "surface has no vertex array");
+    if (!(f & (1ull << 12)) || sf->index_count <= 0)
+        return fail(ctx, PTK_E_UNSUPPORTED, "surface has no index array (mesh_to_pttriangles walks ARRAY_INDEX)");
+    if (f & (0xFull << 6)) return fail(ctx, PTK_E_UNSUPPORTED, "surfaces with custom attribute channels are not decoded");
+    if (sf->vertex_count <= 0 || sf->index_count % 3 != 0) return fail(ctx, PTK_E_INVALID, "bad vertex / index count (%d, %d)", sf->vertex_count, sf->index_count);
+    const bool compressed = (f & (1ull << 29)) != 0;
+    const size_t pos_stride = compressed ? 8 : 12;
+    const bool index32 = sf->vertex_count > 65536;
+    if (!sf->vertex_data || sf->vertex_bytes < (size_t)sf->vertex_count * pos_stride)
+        return fail(ctx, PTK_E_INVALID, "vertex block of %zu bytes is smaller than %d positions of %zu bytes", sf->vertex_bytes, sf->vertex_count, pos_stride);
+    if (!sf->index_data || sf->index_bytes < (size_t)sf->index_count * (index32 ? 4 : 2))
+        return fail(ctx, PTK_E_INVALID, "index block of %zu bytes is smaller than %d indices", sf->index_bytes, sf->index_count);
+    const bool has_uv = (f & (1ull << 4)) != 0;
+    const size_t uv_size = compressed ? 4 : 8;
+    const size_t attr_stride = ((f & (1ull << 3)) ? 4 : 0) + (has_uv ? uv_size : 0) + ((f & (1ull << 5)) ? uv_size : 0);
+    if (has_uv && uvs6 && (!sf->attribute_data || sf->attribute_bytes < (size_t)sf->vertex_count * attr_stride))
+        return fail(ctx, PTK_E_INVALID, "attribute block of %zu bytes is smaller than %d vertices of %zu bytes", sf->attribute_bytes, sf->vertex_count, attr_stride);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n_tri = (uint32_t)(sf->index_count / 3);
+    const size_t vb = (size_t)sf->vertex_count * pos_stride, ib = (size_t)sf->index_count * (index32 ? 4 : 2);
+    const size_t ab = (has_uv && uvs6) ? (size_t)sf->vertex_count * attr_stride : 0;
+    auto pad = [](size_t n) { return (n + 255) & ~(size_t)255; };
+    const size_t o_v = 0, o_a = o_v + pad(vb), o_i = o_a + pad(ab), o_r = o_i + pad(ib), o_b = o_r + pad((size_t)n_tri * 80),
+                 o_u = o_b + pad(aabbs6 ? (size_t)n_tri * 24 : 0), o_e = o_u + pad(uvs6 ? (size_t)n_tri * 24 : 0), total = o_e + 256;
+    uint8_t* d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d, total));
+    struct Guard { uint8_t* p; ~Guard() { (void)hipFree(p); } } guard{d};
+    HIP_TRY(ctx, hipMemcpyAsync(d + o_v, sf->vertex_data, vb, hipMemcpyHostToDevice, ctx->stream));
+    if (ab) HIP_TRY(ctx, hipMemcpyAsync(d + o_a, sf->attribute_data, ab, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d + o_i, sf->index_data, ib, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d + o_e, 0, 256, ctx->stream));
+    PtkMeshJob J;
+    memset(&J, 0, sizeof J);
+    J.vertex_data = d + o_v; J.attribute_data = d + o_a; J.index_data = d + o_i;
+    J.vertex_count = (uint32_t)sf->vertex_count; J.n_triangles = n_tri;
+    J.compressed = compressed; J.index32 = index32; J.has_uv = has_uv && ab;
+    J.uv_rescale = !(sf->uv_scale[0] == 0.0f && sf->uv_scale[1] == 0.0f && sf->uv_scale[2] == 0.0f && sf->uv_scale[3] == 0.0f);
+    J.has_transform = transform12 != nullptr;
+    J.attribute_stride = (uint32_t)attr_stride; J.uv_offset = (f & (1ull << 3)) ? 4u : 0u;
+    memcpy(J.aabb, sf->aabb, sizeof J.aabb);
+    memcpy(J.uv_scale, sf->uv_scale, sizeof J.uv_scale);
+    if (transform12) memcpy(J.transform, transform12, sizeof J.transform);
+    J.material_index = material_index; J.texture_id = texture_id;
+    J.records = d + o_r; J.aabbs = aabbs6 ? (float*)(d + o_b) : nullptr; J.uvs = uvs6 ? (float*)(d + o_u) : nullptr;
+    J.error_count = (uint32_t*)(d + o_e);
+    HIP_TRY(ctx, ptk_launch_mesh(&J, ctx->stream));
+    uint32_t bad = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&bad, d + o_e, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(records80, d + o_r, (size_t)n_tri * 80, hipMemcpyDeviceToHost, ctx->stream));
+    if (aabbs6) HIP_TRY(ctx, hipMemcpyAsync(aabbs6, d + o_b, (size_t)n_tri * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (uvs6) HIP_TRY(ctx, hipMemcpyAsync(uvs6, d + o_u, (size_t)n_tri * 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad) return fail(ctx, PTK_E_INVALID, "%u triangles index past the %d vertices of the surface", bad, sf->vertex_count);
+    *n_triangles = (int32_t)n_tri;
     return PTK_OK;
 }
 

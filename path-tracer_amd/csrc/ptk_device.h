@@ -88,6 +88,8 @@ struct PtkParams {
     const float4* triangles;   // 5 float4 per 80-byte record
     const float4* materials;   // 4 float4 per 64-byte record
     const float4* transforms;  // 4 float4 per 64-byte matrix
+    const float* triangle_uvs; // PTK_OPT_TRIANGLE_UVS: 6 floats per triangle record (corner UVs) from (4,1), else null
+    int n_triangle_uvs;
     const int* live_planes;    // indices of plane records with a non-zero normal
     int n_live_planes;
     int n_spheres, n_planes, n_triangles;  // buffer lengths (records), brute-force mode only
@@ -130,3 +132,21 @@ extern "C" hipError_t ptk_persistent_scratch_init(int device);
 extern "C" void* ptk_persistent_scratch(int device);
 // Display conversion (ptk_display.hip): rgba32f image -> RGBA8, n_pixels * 4 bytes at out_rgba8 (device, 16-byte aligned).
 extern "C" hipError_t ptk_launch_display(const float4* image, void* out_rgba8, size_t n_pixels, int transfer, hipStream_t stream);
+
+// Mesh ingestion (ptk_mesh.hip): one Godot ArrayMesh surface to triangle records; all pointers are device pointers.
+struct PtkMeshJob {
+    const uint8_t* vertex_data;      // positions block: 12 bytes per vertex, or 8 (four unorm16) when compressed
+    const uint8_t* attribute_data;   // per-vertex attributes: [colour 4 B][uv 8 B | 4 B compressed]...
+    const uint8_t* index_data;
+    uint32_t vertex_count, n_triangles;
+    int32_t compressed, index32, has_uv, uv_rescale, has_transform;
+    uint32_t attribute_stride, uv_offset;
+    float aabb[6], uv_scale[4], transform[12];
+    int32_t material_index;
+    uint32_t texture_id;
+    uint8_t* records;                // n_triangles * 80 bytes
+    float* aabbs;                    // n_triangles * 6 (position, size) or null
+    float* uvs;                      // n_triangles * 6 (uv1, uv2, uv3) or null
+    uint32_t* error_count;           // triangles with an index outside the vertex array
+};
+extern "C" hipError_t ptk_launch_mesh(const PtkMeshJob* job, hipStream_t stream);

@@ -906,6 +906,12 @@ PTK_DEV Surf determine_rayhit(const PtkParams& P, Lane& L, const Ray& ray_in, co
             s.normal = normalize3(mul_vm(s.normal, 0.0f, m));
             s.point = mul_mv(matrix, s.point, 1.0f);
         }
+        if (P.triangle_uvs != nullptr && index >= 0 && index < P.n_triangle_uvs) {
+            // real texture coordinates (the shader's TODO at :1071-1072): corner UVs weighted like the point above
+            const float* q = P.triangle_uvs + (size_t)index * 6;
+            s.u = (q[2] * h.u + q[4] * h.v) + q[0] * w;
+            s.v = (q[3] * h.u + q[5] * h.v) + q[1] * w;
+        }
         if (dot3(s.normal, ray_in.d) > 0.0f) s.normal = s.normal * -1.0f;
         if (TRACE) cnt[PTK_CNT_HIT_TRIANGLE]++;
     }

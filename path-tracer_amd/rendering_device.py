@@ -30,10 +30,19 @@ EXPORTS = [
     "ptk_dispatch", "ptk_sync", "ptk_free", "ptk_bvh_build", "ptk_bvh_sizes", "ptk_bvh_read",
     "ptk_trace_enable", "ptk_trace_read", "ptk_last_dispatch_ms", "ptk_dispatch_history_ms", "ptk_image_copy_device",
     "ptk_set_renderer", "ptk_dispatch_traverse_ms", "ptk_update_stats", "ptk_dispatch_noalloc",
-    "ptk_image_read_display",
+    "ptk_image_read_display", "ptk_mesh_to_triangles", "ptk_set_option",
 ]
 
 PTK_RENDERER_AUTO, PTK_RENDERER_SINGLE_KERNEL, PTK_RENDERER_WAVEFRONT, PTK_RENDERER_PERSISTENT = 0, 1, 2, 3
+
+class PtkMeshSurface(C.Structure):
+    """struct ptk_mesh_surface of include/ptk.h."""
+    _fields_ = [("format", C.c_uint64), ("vertex_count", C.c_int32), ("index_count", C.c_int32),
+                ("vertex_data", C.c_void_p), ("vertex_bytes", C.c_size_t),
+                ("attribute_data", C.c_void_p), ("attribute_bytes", C.c_size_t),
+                ("index_data", C.c_void_p), ("index_bytes", C.c_size_t),
+                ("aabb", C.c_float * 6), ("uv_scale", C.c_float * 4)]
+
 
 _lib = None
 
@@ -71,6 +80,10 @@ def load_library() -> C.CDLL:
     lib.ptk_image_read.argtypes = [vp, u64, vp, C.c_size_t]
     lib.ptk_image_read_display.restype = C.c_int
     lib.ptk_image_read_display.argtypes = [vp, u64, vp, C.c_size_t, C.c_int]
+    lib.ptk_mesh_to_triangles.restype = C.c_int
+    lib.ptk_mesh_to_triangles.argtypes = [vp, C.POINTER(PtkMeshSurface), vp, C.c_int32, C.c_uint32, vp, vp, vp, i32p]
+    lib.ptk_set_option.restype = C.c_int
+    lib.ptk_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.ptk_image_update.restype = C.c_int
     lib.ptk_image_update.argtypes = [vp, u64, vp, C.c_size_t]
     lib.ptk_texture_create.restype = u64
@@ -245,6 +258,32 @@ class PtkRenderingDevice:
         self._check(self.lib.ptk_bvh_read(self.ctx, bvh, nodes.ctypes.data, ids.ctypes.data), "ptk_bvh_read")
         return nodes.tobytes(), ids[: ni.value].copy()
 
+    # -- mesh ingestion ----------------------------------------------------------
+    def mesh_to_triangles(self, surface: dict, transform12=None, material_index: int = 1, texture_id: int = 0):
+        """PTObjectContainer.mesh_to_pttriangles on the GPU.  surface: the stored surface dictionary (format,
+        vertex_count, index_count, aabb, uv_scale, vertex_data, attribute_data, index_data as byte arrays).
+        Returns (records [N,20] float32 view of the 80-byte records, aabbs [N,6], uvs [N,6])."""
+        vd = np.ascontiguousarray(surface["vertex_data"], dtype=np.uint8)
+        ad = np.ascontiguousarray(surface.get("attribute_data", np.zeros(0, np.uint8)), dtype=np.uint8)
+        idd = np.ascontiguousarray(surface["index_data"], dtype=np.uint8)
+        s = PtkMeshSurface()
+        s.format = int(surface["format"])
+        s.vertex_count, s.index_count = int(surface["vertex_count"]), int(surface["index_count"])
+        s.vertex_data, s.vertex_bytes = vd.ctypes.data, vd.nbytes
+        s.attribute_data, s.attribute_bytes = (ad.ctypes.data if ad.nbytes else None), ad.nbytes
+        s.index_data, s.index_bytes = idd.ctypes.data, idd.nbytes
+        s.aabb = (C.c_float * 6)(*[float(x) for x in surface["aabb"]])
+        s.uv_scale = (C.c_float * 4)(*[float(x) for x in surface.get("uv_scale", [0, 0, 0, 0])])
+        n = max(s.index_count // 3, 0)
+        rec = np.zeros((max(n, 1), 20), np.float32)
+        aabbs = np.zeros((max(n, 1), 6), np.float32)
+        uvs = np.zeros((max(n, 1), 6), np.float32)
+        t = None if transform12 is None else np.ascontiguousarray(transform12, dtype=np.float32)
+        count = C.c_int32(0)
+        self._check(self.lib.ptk_mesh_to_triangles(self.ctx, C.byref(s), None if t is None else t.ctypes.data, material_index, texture_id,
+                                                   rec.ctypes.data, aabbs.ctypes.data, uvs.ctypes.data, C.byref(count)), "ptk_mesh_to_triangles")
+        return rec[: count.value], aabbs[: count.value], uvs[: count.value]
+
     # -- measurement ------------------------------------------------------------
     def trace_enable(self, flags: int):
         self._check(self.lib.ptk_trace_enable(self.ctx, flags), "ptk_trace_enable")
@@ -271,6 +310,10 @@ class PtkRenderingDevice:
         a, b = C.c_longlong(0), C.c_longlong(0)
         self._check(self.lib.ptk_update_stats(self.ctx, C.byref(a), C.byref(b)), "ptk_update_stats")
         return int(a.value), int(b.value)
+
+    def set_option(self, option: int, value: int):
+        """PTK_OPT_* switches (1 = PTK_OPT_TRIANGLE_UVS: interpolate the corner UVs bound at (4,1))."""
+        self._check(self.lib.ptk_set_option(self.ctx, int(option), int(value)), "ptk_set_option")
 
     def set_renderer(self, renderer: int):
         """PTK_RENDERER_AUTO / _SINGLE_KERNEL / _WAVEFRONT / _PERSISTENT: the schedule used for the next dispatches."""

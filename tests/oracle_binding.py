@@ -34,6 +34,7 @@ class PtoScene(C.Structure):
         ("textures", C.c_void_p), ("n_textures", C.c_int),
         ("order", C.c_int), ("refraction_mode", C.c_int), ("use_emission", C.c_int), ("early_t_break", C.c_int),
         ("n_proc", C.c_int), ("proc_builtin", C.c_void_p),
+        ("triangle_uvs", C.c_void_p), ("n_triangle_uvs", C.c_int),
     ]
 
 
@@ -103,7 +104,7 @@ PROC_BUILTIN = {"checker_board.comp": 1, "checker_board_spatial.comp": 2}
 
 
 def render(packed, push: bytes, image: np.ndarray, groups_x: int, groups_y: int, refraction_mode=2, use_emission=False,
-           early_t_break=False, trace=True, nthreads: int = 0, order=None):
+           early_t_break=False, trace=True, nthreads: int = 0, order=None, triangle_uvs=None):
     """One dispatch on the oracle.  image: [H,W,4] float32, updated in place.  Returns dict with
     primary ids, per-pixel stats and totals when trace is set."""
     lib = load()
@@ -138,6 +139,10 @@ def render(packed, push: bytes, image: np.ndarray, groups_x: int, groups_y: int,
     pb = np.array([PROC_BUILTIN[os.path.basename(p)] for p in packed.proc_tex_paths] or [0], dtype=np.int32)
     keep.append(pb)
     s.n_proc, s.proc_builtin = len(packed.proc_tex_paths), pb.ctypes.data
+    if triangle_uvs is not None:  # the real-UV extension: [N,6] float32, one row per triangle record
+        tu = np.ascontiguousarray(triangle_uvs, dtype=np.float32).reshape(-1, 6)
+        keep.append(tu)
+        s.triangle_uvs, s.n_triangle_uvs = tu.ctypes.data, tu.shape[0]
     out = {}
     tr = PtoTrace()
     if trace:

@@ -138,6 +138,46 @@ def decode_array_mesh(raw_surfaces: str) -> np.ndarray:
     return verts[idx.astype(np.int64)].reshape(-1, 3, 3).astype(np.float32)
 
 
+def raw_surface(raw_surfaces: str) -> dict:
+    """Surface 0 of an ArrayMesh as the .tscn stores it (the dictionary RenderingServer.mesh_add_surface takes):
+    format flags, counts, aabb, uv_scale and the vertex / attribute / index byte blocks, undecoded."""
+    def grab(key):
+        m = re.search(r'"%s": PackedByteArray\("([^"]*)"\)' % key, raw_surfaces)
+        return np.frombuffer(base64.b64decode(m.group(1)), dtype=np.uint8) if m else np.zeros(0, np.uint8)
+
+    def vec(key, ctor):
+        m = re.search(r'"%s": %s\(([^)]*)\)' % (key, ctor), raw_surfaces)
+        return np.array([float(x) for x in m.group(1).split(",")], dtype=np.float32) if m else None
+
+    uv_scale = vec("uv_scale", "Vector4")
+    return {
+        "format": np.uint64(int(re.search(r'"format": (\d+)', raw_surfaces).group(1))),
+        "vertex_count": np.int32(int(re.search(r'"vertex_count": (\d+)', raw_surfaces).group(1))),
+        "index_count": np.int32(int(re.search(r'"index_count": (\d+)', raw_surfaces).group(1))),
+        "aabb": vec("aabb", "AABB"),
+        "uv_scale": uv_scale if uv_scale is not None else np.zeros(4, np.float32),
+        "vertex_data": grab("vertex_data"), "attribute_data": grab("attribute_data"), "index_data": grab("index_data"),
+    }
+
+
+MESH_SURFACES = [  # (fixture name, scene file, name of the ArrayMesh sub-resource's owner node type)
+    ("dragon", "test_models/dragon low poly/dragon_import.tscn"),
+    ("grimchild", "test_models/grimchild/grimchild_test.tscn"),
+]
+
+
+def extract_mesh_surfaces():
+    out_dir = os.path.join(OUT, "..", "meshes")
+    os.makedirs(out_dir, exist_ok=True)
+    for name, rel in MESH_SURFACES:
+        secs = parse_tscn(os.path.join(REF, rel))
+        meshes = [s for s in secs if s["kind"] == "sub_resource" and s["attrs"].get("type") == "ArrayMesh" and "_surfaces" in s["raw"]]
+        # the render mesh is the sub-resource with the most vertices (a welded shadow mesh may precede it)
+        surf = max((raw_surface(m["raw"]["_surfaces"]) for m in meshes), key=lambda d: int(d["vertex_count"]))
+        np.savez_compressed(os.path.join(out_dir, name + "_surface.npz"), **surf)
+        print(name, "surface: format", hex(int(surf["format"])), "vertices", int(surf["vertex_count"]), "indices", int(surf["index_count"]))
+
+
 class SceneExtractor:
     def __init__(self, path: str):
         self.path = path
@@ -273,6 +313,7 @@ def main():
         with open(os.path.join(OUT, name + ".json"), "w") as f:
             json.dump(d, f, indent=1)
         print(name, "nodes:", len(d["nodes"]), "materials:", len(d["materials"]), "textures:", len(d["textures"]))
+    extract_mesh_surfaces()
 
 
 if __name__ == "__main__":
