@@ -83,6 +83,22 @@ struct ptk_ctx {
     std::vector<int32_t> node_slot;  // node index -> block * 8 + child slot holding its box, -1 if none
     std::vector<int32_t> tri_slot, sph_slot;  // primitive index -> object-id slot holding its record, -1 if none
     long long full_validations = 0, patched_updates = 0;
+    // Updates waiting for the next flush (before a dispatch or a read): byte ranges of buffers whose shadow copy
+    // already holds the new bytes, and the pieces of the derived structures their patches touched.
+    struct PendingRange { uint64_t handle; size_t offset, nbytes; };
+    std::vector<PendingRange> pending;
+    std::vector<uint32_t> dirty_blocks, dirty_slots;   // block indices / object-id slots whose host mirror changed
+    std::vector<uint8_t> block_is_dirty, slot_is_dirty;
+    bool live_planes_dirty = false;
+    std::vector<int> h_live_planes;
+    size_t live_planes_capacity = 0;
+    static constexpr size_t kStageBytes = (size_t)4 << 20;
+    uint8_t* h_stage[2] = {nullptr, nullptr};  // pinned
+    uint8_t* d_stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    bool stage_used[2] = {false, false};
+    int stage_next = 0;
+    long long flushes = 0;
     // AUTO renderer choice: all schedules give the same image, so the first dispatches of a workload
     // are used to time each of them (twice) and the fastest one is kept until the workload changes
     struct AutoChoice {
@@ -145,6 +161,7 @@ static Object* bound_buffer(ptk_ctx* ctx, int set, int binding) {
 }
 
 static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, const std::vector<uint8_t>& before);
+static int flush_updates(ptk_ctx* ctx);
 static void derive_chain(ptk_ctx* ctx);
 
 extern "C" {
@@ -174,6 +191,9 @@ ptk_ctx* ptk_create(int device_ordinal) {
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < ptk_ctx::kTimingRing; i++)
         ok = hipEventCreate(&ctx->ev0[i]) == hipSuccess && hipEventCreate(&ctx->ev1[i]) == hipSuccess;
+    for (int k = 0; ok && k < 2; k++)
+        ok = hipHostMalloc((void**)&ctx->h_stage[k], ptk_ctx::kStageBytes) == hipSuccess &&
+             hipMalloc((void**)&ctx->d_stage[k], ptk_ctx::kStageBytes) == hipSuccess && hipEventCreate(&ctx->stage_ev[k]) == hipSuccess;
     hipDeviceProp_t prop;
     ok = ok && hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess;
     if (ok) ctx->n_cus = prop.multiProcessorCount;
@@ -213,6 +233,11 @@ void ptk_destroy(ptk_ctx* ctx) {
     if (ctx->d_wf_spill) (void)hipFree(ctx->d_wf_spill);
     if (ctx->d_pixel_counter) (void)hipFree(ctx->d_pixel_counter);
     if (ctx->d_display) (void)hipFree(ctx->d_display);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->h_stage[k]) (void)hipHostFree(ctx->h_stage[k]);
+        if (ctx->d_stage[k]) (void)hipFree(ctx->d_stage[k]);
+        if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
+    }
     for (int i = 0; i < ptk_ctx::kTimingRing; i++) {
         if (ctx->wf_ev[i]) {
             for (int k = 0; k < 2 * PTK_WF_MAX_ITER; k++) (void)hipEventDestroy(ctx->wf_ev[i][k]);
@@ -291,11 +316,13 @@ int ptk_buffer_update(ptk_ctx* ctx, uint64_t buffer, size_t offset, const void* 
     if (!bytes || offset > o->nbytes || nbytes > o->nbytes - offset)
         return fail(ctx, PTK_E_INVALID, "update of %zu bytes at %zu exceeds buffer of %zu bytes", nbytes, offset, o->nbytes);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (nbytes == 0) return PTK_OK;
     const std::vector<uint8_t> before(o->shadow.begin() + offset, o->shadow.begin() + offset + nbytes);
     memcpy(o->shadow.data() + offset, bytes, nbytes);
-    // stream-ordered after earlier dispatches; the source is the shadow copy, which outlives the call
-    HIP_TRY(ctx, hipMemcpyAsync((uint8_t*)o->dev + offset, o->shadow.data() + offset, nbytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // The new bytes live in the shadow copy; the device copy follows at the next flush (before the next dispatch
+    // or read), all pending ranges in one transfer, stream-ordered after the dispatches already queued.  Nothing
+    // here waits for the GPU.
+    ctx->pending.push_back({buffer, offset, nbytes});
     const int patched = patch_derived(ctx, o, offset, nbytes, before);
     if (patched < 0) { ctx->dirty = true; return patched; }
     if (patched == 0) ctx->dirty = true;
@@ -309,6 +336,7 @@ int ptk_buffer_read(ptk_ctx* ctx, uint64_t buffer, size_t offset, void* dst, siz
     if (!o) return fail(ctx, PTK_E_INVALID, "unknown buffer handle %llu", (unsigned long long)buffer);
     if (!dst || offset > o->nbytes || nbytes > o->nbytes - offset) return fail(ctx, PTK_E_INVALID, "read out of range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int r = flush_updates(ctx); if (r != PTK_OK) return r; }
     HIP_TRY(ctx, hipMemcpyAsync(dst, (uint8_t*)o->dev + offset, nbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PTK_OK;
@@ -410,6 +438,7 @@ int ptk_free(ptk_ctx* ctx, uint64_t handle) {
     auto it = ctx->objects.find(handle);
     if (it == ctx->objects.end()) return fail(ctx, PTK_E_INVALID, "unknown handle %llu", (unsigned long long)handle);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int r = flush_updates(ctx); if (r != PTK_OK) return r; }  // nothing may still point at this object's memory
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     Object* o = it->second.get();
     for (auto b = ctx->bound.begin(); b != ctx->bound.end();) {
@@ -452,17 +481,111 @@ inline int sext(int v, int off, int bits) { return ((int)((uint32_t)v << (32 - o
 // Planes with a non-zero normal, in index order (the others can never be hit, ray_tracer.comp:859).
 static int refresh_live_planes(ptk_ctx* ctx, Object* pln) {
     const int n_pln = (int)(pln->nbytes / 32);
-    std::vector<int> live;
+    std::vector<int>& live = ctx->h_live_planes;
+    live.clear();
     for (int i = 0; i < n_pln; i++) {
         float nrm[3];
         memcpy(nrm, pln->shadow.data() + (size_t)i * 32, 12);
         if (!(nrm[0] == 0.0f && nrm[1] == 0.0f && nrm[2] == 0.0f)) live.push_back(i);
     }
-    if (ctx->d_live_planes) { (void)hipFree(ctx->d_live_planes); ctx->d_live_planes = nullptr; }
     ctx->n_live_planes = (int)live.size();
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_live_planes, std::max<size_t>(4, live.size() * 4)));
-    if (!live.empty()) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_live_planes, live.data(), live.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((size_t)n_pln > ctx->live_planes_capacity || !ctx->d_live_planes) {  // sized for every plane record: edits never reallocate
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_live_planes) { (void)hipFree(ctx->d_live_planes); ctx->d_live_planes = nullptr; }
+        ctx->live_planes_capacity = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_live_planes, std::max<size_t>(16, (size_t)n_pln * 4)));
+        ctx->live_planes_capacity = (size_t)n_pln;
+    }
+    ctx->live_planes_dirty = true;  // uploaded with the next flush
+    return PTK_OK;
+}
+
+// Brings everything the pending updates touched to the GPU, stream-ordered: byte ranges of the bound buffers
+// (merged per buffer, taken from the shadow copies), changed node blocks, leaf records and the live-plane
+// list (from their host mirrors).  Small pieces travel together in a pinned staging block -- a table of
+// destinations plus payloads, one transfer, one scatter kernel; a piece larger than a quarter of the block
+// is copied on its own.  No allocation, no wait for the GPU except when both staging blocks are still in flight.
+static int flush_updates(ptk_ctx* ctx) {
+    if (ctx->pending.empty() && ctx->dirty_blocks.empty() && ctx->dirty_slots.empty() && !ctx->live_planes_dirty) return PTK_OK;
+    struct Piece { uint8_t* dst; const uint8_t* src; size_t n; };
+    std::vector<Piece> pieces;
+    {   // byte ranges, merged per buffer
+        std::sort(ctx->pending.begin(), ctx->pending.end(), [](const ptk_ctx::PendingRange& a, const ptk_ctx::PendingRange& b) {
+            return a.handle != b.handle ? a.handle < b.handle : a.offset < b.offset;
+        });
+        for (size_t i = 0; i < ctx->pending.size();) {
+            const uint64_t h = ctx->pending[i].handle;
+            size_t lo = ctx->pending[i].offset, hi = lo + ctx->pending[i].nbytes;
+            size_t j = i + 1;
+            Object* o = find(ctx, h, Kind::Buffer);
+            for (; j <= ctx->pending.size(); j++) {
+                const bool more = j < ctx->pending.size() && ctx->pending[j].handle == h;
+                if (more && ctx->pending[j].offset <= hi) { hi = std::max(hi, ctx->pending[j].offset + ctx->pending[j].nbytes); continue; }
+                if (o) pieces.push_back({(uint8_t*)o->dev + lo, o->shadow.data() + lo, hi - lo});
+                if (!more) break;
+                lo = ctx->pending[j].offset;
+                hi = lo + ctx->pending[j].nbytes;
+            }
+            i = j;
+        }
+        ctx->pending.clear();
+    }
+    auto runs = [&](std::vector<uint32_t>& idx, std::vector<uint8_t>& flag, uint8_t* dev, const uint8_t* host, size_t unit) {
+        std::sort(idx.begin(), idx.end());
+        for (size_t i = 0; i < idx.size();) {
+            size_t j = i + 1;
+            while (j < idx.size() && idx[j] == idx[j - 1] + 1) j++;
+            if (dev) pieces.push_back({dev + (size_t)idx[i] * unit, host + (size_t)idx[i] * unit, (j - i) * unit});
+            i = j;
+        }
+        for (uint32_t k : idx) flag[k] = 0;
+        idx.clear();
+    };
+    runs(ctx->dirty_blocks, ctx->block_is_dirty, (uint8_t*)ctx->d_blocks, (const uint8_t*)ctx->h_blocks.data(), 256);
+    runs(ctx->dirty_slots, ctx->slot_is_dirty, (uint8_t*)ctx->d_leaf_records, (const uint8_t*)ctx->h_leaf_records.data(), 48);
+    if (ctx->live_planes_dirty) {
+        if (!ctx->h_live_planes.empty() && ctx->d_live_planes)
+            pieces.push_back({(uint8_t*)ctx->d_live_planes, (const uint8_t*)ctx->h_live_planes.data(), ctx->h_live_planes.size() * 4});
+        ctx->live_planes_dirty = false;
+    }
+    const size_t cap = ptk_ctx::kStageBytes;
+    size_t i = 0;
+    while (i < pieces.size()) {
+        if (pieces[i].n > cap / 4) {  // large piece: its own copy (the runtime stages pageable memory before it returns)
+            HIP_TRY(ctx, hipMemcpyAsync(pieces[i].dst, pieces[i].src, pieces[i].n, hipMemcpyHostToDevice, ctx->stream));
+            i++;
+            continue;
+        }
+        // a batch: as many following small pieces as fit into one staging block
+        size_t j = i, payload = 0;
+        while (j < pieces.size() && pieces[j].n <= cap / 4) {
+            const size_t need = (j - i + 1) * sizeof(PtkScatterEntry) + 16 + payload + ((pieces[j].n + 15) & ~(size_t)15);
+            if (need > cap) break;
+            payload += (pieces[j].n + 15) & ~(size_t)15;
+            j++;
+        }
+        const int k = ctx->stage_next;
+        ctx->stage_next ^= 1;
+        if (ctx->stage_used[k]) HIP_TRY(ctx, hipEventSynchronize(ctx->stage_ev[k]));  // (the transfer two batches ago)
+        uint8_t* hs = ctx->h_stage[k];
+        const size_t n_ent = j - i;
+        size_t off = (n_ent * sizeof(PtkScatterEntry) + 15) & ~(size_t)15;
+        for (size_t e = 0; e < n_ent; e++) {
+            PtkScatterEntry ent;
+            ent.dst = (uint64_t)(uintptr_t)pieces[i + e].dst;
+            ent.src_offset = (uint32_t)off;
+            ent.nbytes = (uint32_t)pieces[i + e].n;
+            memcpy(hs + e * sizeof(PtkScatterEntry), &ent, sizeof ent);
+            memcpy(hs + off, pieces[i + e].src, pieces[i + e].n);
+            off += (pieces[i + e].n + 15) & ~(size_t)15;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage[k], hs, off, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->stage_ev[k], ctx->stream));
+        ctx->stage_used[k] = true;
+        HIP_TRY(ctx, ptk_launch_scatter(ctx->d_stage[k], (uint32_t)n_ent, ctx->stream));
+        i = j;
+    }
+    ctx->flushes++;
     return PTK_OK;
 }
 
@@ -513,9 +636,8 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
             const uint8_t* p = o->shadow.data() + i * rec;
             if (tri) { memcpy(r + 0, p + 0, 12); memcpy(r + 4, p + 16, 12); memcpy(r + 8, p + 32, 12); }
             else { memcpy(r + 0, p, 12); memcpy(r + 4, p + 12, 4); }
-            HIP_TRY(ctx, hipMemcpyAsync((float*)ctx->d_leaf_records + (size_t)slot * 12, r, 48, hipMemcpyHostToDevice, ctx->stream));
+            if (!ctx->slot_is_dirty[slot]) { ctx->slot_is_dirty[slot] = 1; ctx->dirty_slots.push_back((uint32_t)slot); }
         }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return 1;
     }
     if (o->set == PTK_SET_BVH && o->binding == 0) {  // nodes: boxes may move, ids and transform indices may not
@@ -540,12 +662,10 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
             const size_t blk = (size_t)(ns >> 3) * 64, l = (size_t)(ns & 7);
             float* h = ctx->h_blocks.data() + blk;
             const int plane_of[6] = {0, 1, 2, 4, 5, 6};
-            for (int k = 0; k < 6; k++) {
-                h[k * 8 + l] = box[plane_of[k]];
-                HIP_TRY(ctx, hipMemcpyAsync((float*)ctx->d_blocks + blk + k * 8 + l, h + k * 8 + l, 4, hipMemcpyHostToDevice, ctx->stream));
-            }
+            for (int k = 0; k < 6; k++) h[k * 8 + l] = box[plane_of[k]];
+            const uint32_t bi = (uint32_t)(ns >> 3);
+            if (!ctx->block_is_dirty[bi]) { ctx->block_is_dirty[bi] = 1; ctx->dirty_blocks.push_back(bi); }
         }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         derive_chain(ctx);  // a patched box may be one of the chain's
         return 1;
     }
@@ -787,6 +907,11 @@ static int validate_scene(ptk_ctx* ctx) {
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_leaf_records, leaf_records.size() * 4));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_leaf_records, leaf_records.data(), leaf_records.size() * 4, hipMemcpyHostToDevice, ctx->stream));
 
+    // the derived structures were uploaded whole: nothing of them is pending any more
+    ctx->dirty_blocks.clear();
+    ctx->dirty_slots.clear();
+    ctx->block_is_dirty.assign(ctx->h_blocks.size() / 64 + 1, 0);
+    ctx->slot_is_dirty.assign((size_t)std::max(n_ids, 1), 0);
     { int r = refresh_live_planes(ctx, pln); if (r != PTK_OK) return r; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // persistent waves per CU of both persistent kernels at this scene's LDS need (window + one spare row)
@@ -932,6 +1057,7 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     if (!img) return fail(ctx, PTK_E_STATE, "no image bound at (0,0)");
     if (ctx->dirty) { int r = validate_scene(ctx); if (r != PTK_OK) return r; }
     if (ctx->textures_dirty) { int r = refresh_textures(ctx); if (r != PTK_OK) return r; }
+    { int r = flush_updates(ctx); if (r != PTK_OK) return r; }
 
     PtkParams P;
     { int r = fill_params(ctx, push128, P); if (r != PTK_OK) return r; }
@@ -1149,6 +1275,7 @@ int ptk_dispatch_noalloc(ptk_ctx* ctx, const void* push128, int groups_x, int gr
     if (ctx->dirty || ctx->textures_dirty)
         return fail(ctx, PTK_E_STATE, "the bound scene changed since the last ptk_dispatch: its derived tables are rebuilt (and allocated) "
                                       "there; call ptk_dispatch once, then ptk_dispatch_noalloc");
+    { int r = flush_updates(ctx); if (r != PTK_OK) return r; }  // patched edits: staged through preallocated blocks
     PtkParams P;
     { int r = fill_params(ctx, push128, P); if (r != PTK_OK) return r; }
     if (ctx->trace_flags != 0 || !persistent_covers(ctx, P.push, false))

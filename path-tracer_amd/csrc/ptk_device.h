@@ -150,3 +150,11 @@ struct PtkMeshJob {
     uint32_t* error_count;           // triangles with an index outside the vertex array
 };
 extern "C" hipError_t ptk_launch_mesh(const PtkMeshJob* job, hipStream_t stream);
+
+// Batched updates (ptk_update.hip): a staging block = n_entries PtkScatterEntry, then payload bytes.
+struct PtkScatterEntry {
+    uint64_t dst;         // device address
+    uint32_t src_offset;  // of the payload inside the staging block (16-byte aligned)
+    uint32_t nbytes;
+};
+extern "C" hipError_t ptk_launch_scatter(const void* d_stage, uint32_t n_entries, hipStream_t stream);

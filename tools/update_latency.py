@@ -1,0 +1,50 @@
+"""Host time of the incremental edit path: N single-record buffer_update calls followed by one dispatch
+(which flushes them in one staged transfer), for N = 1, 64, 4096 dirty records, on the bench scene's
+triangle buffer and on its node buffer.  Prints a markdown table (development aid)."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pta = importlib.import_module("path-tracer_amd")
+wd = pta.work_dispatcher
+w, h = 1920, 1080
+scene = pta.scenes.atrium_scene(262144, seed=7)
+rd = pta.PtkRenderingDevice(0)
+rd.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
+disp = wd.PTWorkDispatcher(rd)
+disp.set_scene(scene)
+disp.create_buffers(w, h, order=8)
+disp.load_shader()
+win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=8, max_refraction_bounces=4)
+for k in range(3):
+    win.frame = k
+    disp.create_compute_list(win, scene.camera, wd.sample_time(k), sync=True)
+tri = np.frombuffer(disp.packed.triangles, np.uint8)
+nodes = np.frombuffer(disp.packed.bvh, np.uint8)
+n_nodes = len(nodes) // 32
+print("| edit | dirty records | buffer_update calls, host ms | flush inside the next dispatch call, host ms | per record us |")
+print("|---|---|---|---|---|")
+rng = np.random.default_rng(1)
+for what, buf, rec, data, count in (("triangle record (80 B)", disp.triangle_buffer, 80, tri, 262144), ("node box (32 B)", disp.bvh_buffer, 32, nodes, n_nodes)):
+    for n in (1, 64, 4096):
+        picks = rng.choice(np.arange(1, count - 1), size=n, replace=False)
+        best_u, best_f = 1e9, 1e9
+        for rep in range(5):
+            rd.sync()
+            t0 = time.perf_counter()
+            for i in picks:
+                o = int(i) * rec
+                rd.lib.ptk_buffer_update(rd.ctx, buf, o, data[o:o + rec].ctypes.data, rec)
+            t1 = time.perf_counter()
+            disp.create_compute_list(win, scene.camera, wd.sample_time(1))  # returns once the work is queued
+            t2 = time.perf_counter()
+            rd.sync()
+            best_u, best_f = min(best_u, t1 - t0), min(best_f, t2 - t1)
+        print("| %s | %d | %.3f | %.3f | %.2f |" % (what, n, best_u * 1e3, best_f * 1e3, (best_u + best_f) * 1e6 / n))
+full, patched = rd.update_stats()
+print("full validations", full, "patched updates", patched)
