@@ -144,6 +144,31 @@ int ptk_bvh_sizes(ptk_ctx* ctx, uint64_t bvh, int32_t* n_nodes, int32_t* n_objec
  * 32 bytes per node in index_tree order, and the object id table. */
 int ptk_bvh_read(ptk_ctx* ctx, uint64_t bvh, void* node_bytes, int32_t* object_ids);
 
+/* Replaces the tree -> bytes -> buffer step of PTWorkDispatcher.create_buffers for a tree built here
+ * (create_object_id_buffer + create_bvh_buffer, pt_work_dispatcher.gd:184-185,723-758): the node bytes and the id
+ * table are written from the builder's device buffers straight into two new storage buffers bound at (3,0) and
+ * (3,1), sized and padded as the plugin sizes them, without a trip through host memory.  The handles come back
+ * for buffer_read / free_rid.  The bound tree stays refittable (ptk_bvh_refit) until the caller edits or
+ * replaces these two buffers itself. */
+int ptk_bvh_bind(ptk_ctx* ctx, uint64_t bvh, uint64_t* nodes_buffer, uint64_t* ids_buffer);
+
+/* Replaces PTBVHTree.update_aabb / update_mesh_socket_aabb and the dirty-node uploads that follow them
+ * (proprietary_dataclasses/bvh_trees/pt_bvh_tree.gd:254-271,873-882; pt_renderer.gd:771-788) for the tree bound
+ * with ptk_bvh_bind.  Each event is one call of the reference: an object whose get_bvh_aabb() changed
+ * (object_id = its id, v[0..5] = the new box as position.xyz, size.xyz) or a mesh whose transform changed
+ * (object_id = mesh index | PTK_REFIT_MESH << 24, v[0..11] = the new Transform3D as basis rows + origin).
+ * Events are applied in order with the reference's rule -- recompute the node's box, stop unless it differs from
+ * the old one by more than AABB.is_equal_approx allows, otherwise queue the node and go on with the parent --
+ * on the GPU, all events of the call at once.  The queued nodes' records are rewritten in the bound node buffer
+ * (and in what the kernels derive from it); *n_nodes_updated = how many.  The primitive records of moved objects
+ * are the caller's to update (ptk_buffer_update), as in the plugin. */
+typedef struct ptk_refit_event {
+    int32_t object_id;
+    float v[12];
+} ptk_refit_event;
+enum { PTK_REFIT_MESH = 4 };
+int ptk_bvh_refit(ptk_ctx* ctx, const ptk_refit_event* events, int n_events, int32_t* n_nodes_updated);
+
 /* Replaces PTObjectContainer.mesh_to_pttriangles (proprietary_dataclasses/pt_object_container.gd:163-186: one
  * PTTriangle per index triplet of Mesh.surface_get_arrays(0)) together with what those triangles feed:
  * PTTriangle.to_byte_array (public/primitives/pt_triangle.gd:125-150) and get_bvh_aabb (pt_triangle.gd:107-112,

@@ -574,6 +574,91 @@ int pbo_flatten(pbo_tree* t, uint8_t* node_bytes_out, int32_t* object_ids_out) {
     return 0;
 }
 
+/* ---- incremental refit ----------------------------------------------------
+ * BVHNode.update_aabb (pt_bvh_tree.gd:873-882), reached from PTBVHTree.update_aabb(object) (:254-260) and
+ * update_mesh_socket_aabb(mesh) (:263-270): recompute the node's box; if it is not is_equal_approx to the old
+ * one, queue the node's index for upload (:295-302) and update the parent.  The upload later writes
+ * to_byte_array() of every queued node (pt_renderer.gd:771-788), i.e. the box the node has by then.
+ * Godot's Math::is_equal_approx(a, b) (core/math/math_funcs.h): equal, or |a - b| below max(1e-5 * |a|, 1e-5);
+ * AABB::is_equal_approx compares position and size component-wise.  Not part of /root/reference: restated. */
+static int approx1(float a, float b) {
+    if (a == b) return 1;
+    float tol = 0.00001f * fabsf(a);
+    if (tol < 0.00001f) tol = 0.00001f;
+    return fabsf(a - b) < tol;
+}
+static int aabb_equal_approx(AABB a, AABB b) {
+    return approx1(a.position.x, b.position.x) && approx1(a.position.y, b.position.y) && approx1(a.position.z, b.position.z) &&
+           approx1(a.size.x, b.size.x) && approx1(a.size.y, b.size.y) && approx1(a.size.z, b.size.z);
+}
+static void node_update_aabb(Node* n, uint8_t* queued_flag, int32_t* queued, int* n_queued) {
+    AABB old = n->aabb;
+    node_set_aabb(n);
+    if (!aabb_equal_approx(n->aabb, old)) {
+        if (!queued_flag[n->index]) { queued_flag[n->index] = 1; queued[(*n_queued)++] = n->index; }
+        if (n->parent) node_update_aabb(n->parent, queued_flag, queued, n_queued);
+    }
+}
+typedef struct { int32_t id; int tree; int idx; } ObjKey;
+static int objkey_cmp(const void* a, const void* b) {
+    int32_t x = ((const ObjKey*)a)->id, y = ((const ObjKey*)b)->id;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+/* events: object_ids[j] = an object's id with v12[j*12 .. +6) its new box, or mesh index | 4 << 24 with
+ * v12[j*12 .. +12) the mesh's new transform.  node_bytes (the image pbo_flatten wrote, flattened before this
+ * call) gets the records of the queued nodes rewritten; queued_out (room for pbo_node_count ints) their
+ * indices in queue order.  Returns the number of queued nodes, or -1 for an unknown object / mesh. */
+int pbo_refit(pbo_tree* t, int n_events, const int32_t* object_ids, const float* v12, uint8_t* node_bytes_io, int32_t* queued_out) {
+    int n_trees = 1 + t->n_meshes;
+    pbo_tree** trees = (pbo_tree**)malloc(sizeof(*trees) * n_trees);
+    trees[0] = t;
+    for (int m = 0; m < t->n_meshes; m++) trees[1 + m] = t->meshes[m];
+    size_t total = 0;
+    for (int k = 0; k < n_trees; k++) total += trees[k]->n_objects;
+    ObjKey* keys = (ObjKey*)malloc(sizeof(ObjKey) * (total ? total : 1));
+    Node*** leaf_of = (Node***)malloc(sizeof(Node**) * n_trees);
+    size_t w = 0;
+    for (int k = 0; k < n_trees; k++) {
+        pbo_tree* tr = trees[k];
+        leaf_of[k] = (Node**)calloc(tr->n_objects ? tr->n_objects : 1, sizeof(Node*));
+        for (int i = 0; i < tr->n_objects; i++) { keys[w].id = tr->obj_id[i]; keys[w].tree = k; keys[w].idx = i; w++; }
+        for (int i = 0; i < tr->n_all; i++) {
+            Node* nd = tr->all_nodes[i];
+            for (int j = 0; j < nd->n_objects; j++) leaf_of[k][nd->objects[j]] = nd;
+        }
+    }
+    qsort(keys, total, sizeof(ObjKey), objkey_cmp);
+    int n_nodes = pbo_node_count(t);
+    uint8_t* flag = (uint8_t*)calloc(n_nodes, 1);
+    Node** by_index = (Node**)calloc(n_nodes, sizeof(Node*));
+    for (int k = 0; k < n_trees; k++)
+        for (int i = 0; i < trees[k]->n_all; i++) { Node* nd = trees[k]->all_nodes[i]; if (nd->index >= 0 && nd->index < n_nodes) by_index[nd->index] = nd; }
+    int n_queued = 0, rc = 0;
+    for (int j = 0; j < n_events && rc == 0; j++) {
+        int32_t id = object_ids[j];
+        const float* v = v12 + (size_t)j * 12;
+        if (((uint32_t)id >> 24) == 4u) {
+            int mi = id & 0x00FFFFFF;
+            pbo_tree* mt = NULL;
+            for (int m = 0; m < t->n_meshes; m++) if (t->meshes[m]->mesh_index == mi) mt = t->meshes[m];
+            if (!mt) { rc = -1; break; }
+            memcpy(mt->mesh_transform, v, sizeof(float) * 12);
+            node_update_aabb(mt->root->parent, flag, queued_out, &n_queued);
+        } else {
+            ObjKey probe; probe.id = id;
+            ObjKey* hit = (ObjKey*)bsearch(&probe, keys, total, sizeof(ObjKey), objkey_cmp);
+            if (!hit || !leaf_of[hit->tree][hit->idx]) { rc = -1; break; }
+            AABB nb = {v3(v[0], v[1], v[2]), v3(v[3], v[4], v[5])};
+            trees[hit->tree]->obj_aabb[hit->idx] = nb;
+            node_update_aabb(leaf_of[hit->tree][hit->idx], flag, queued_out, &n_queued);
+        }
+    }
+    if (rc == 0) for (int q = 0; q < n_queued; q++) node_bytes(t, by_index[queued_out[q]], node_bytes_io + (size_t)queued_out[q] * 32);
+    for (int k = 0; k < n_trees; k++) free(leaf_of[k]);
+    free(leaf_of); free(keys); free(flag); free(by_index); free(trees);
+    return rc ? rc : n_queued;
+}
+
 void pbo_free(pbo_tree* t) {
     if (!t) return;
     for (int m = 0; m < t->n_meshes; m++) pbo_free(t->meshes[m]);

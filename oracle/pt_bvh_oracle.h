@@ -38,6 +38,8 @@ int pbo_node_count(const pbo_tree* t);
 int pbo_object_id_count(const pbo_tree* t);
 void pbo_counts(const pbo_tree* t, int32_t* out4); /* inner, leaf, object, mesh_object */
 int pbo_flatten(pbo_tree* t, uint8_t* node_bytes_out, int32_t* object_ids_out);
+/* The reference's incremental refit (update_aabb chains) on a flattened tree; see pt_bvh_oracle.c. */
+int pbo_refit(pbo_tree* t, int n_events, const int32_t* object_ids, const float* v12, uint8_t* node_bytes_io, int32_t* queued_out);
 void pbo_free(pbo_tree* t);
 
 int pbo_is_aabb_valid(const float* a6);

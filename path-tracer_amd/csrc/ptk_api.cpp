@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -32,6 +33,14 @@ struct Object {
     std::shared_ptr<PtkBvh> bvh;  // shared with every scene tree that merged it as a mesh
 };
 
+// The tree bound with ptk_bvh_bind, kept refittable until its buffers are edited or rebound behind its back.
+struct BoundTree {
+    uint64_t nodes_handle = 0, ids_handle = 0;
+    std::shared_ptr<PtkBvh> bvh;
+    std::unique_ptr<PtkRefitState> state;
+    std::vector<std::pair<int32_t, int32_t>> slot_of_object;  // (object id, slot in the id table), sorted; built at the first refit
+};
+
 struct Slot {
     uint64_t handle = 0;
 };
@@ -49,6 +58,8 @@ struct ptk_ctx {
     uint64_t next_handle = 1;
     std::map<std::pair<int, int>, uint64_t> bound;  // (set, binding) -> buffer handle
     uint64_t image = 0;
+    std::unique_ptr<BoundTree> bound_tree;
+    bool in_refit = false;  // the library's own node updates do not invalidate the bound tree
     std::map<int, uint64_t> texture_slots;
     // configuration (ptk_configure)
     int order = 8, refraction_mode = 2, use_emission = 0, early_t_break = 0;
@@ -305,6 +316,7 @@ uint64_t ptk_buffer_create(ptk_ctx* ctx, int set, int binding, const void* bytes
     uint64_t h = ctx->next_handle++;
     ctx->objects[h] = std::move(o);
     ctx->bound[{set, binding}] = h;
+    if (set == PTK_SET_BVH) ctx->bound_tree.reset();  // another tree is bound now
     ctx->dirty = true;
     return h;
 }
@@ -317,6 +329,8 @@ int ptk_buffer_update(ptk_ctx* ctx, uint64_t buffer, size_t offset, const void* 
         return fail(ctx, PTK_E_INVALID, "update of %zu bytes at %zu exceeds buffer of %zu bytes", nbytes, offset, o->nbytes);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (nbytes == 0) return PTK_OK;
+    if (ctx->bound_tree && !ctx->in_refit && (buffer == ctx->bound_tree->nodes_handle || buffer == ctx->bound_tree->ids_handle))
+        ctx->bound_tree.reset();  // edited by the caller: the library no longer knows the boxes behind these bytes
     const std::vector<uint8_t> before(o->shadow.begin() + offset, o->shadow.begin() + offset + nbytes);
     memcpy(o->shadow.data() + offset, bytes, nbytes);
     // The new bytes live in the shadow copy; the device copy follows at the next flush (before the next dispatch
@@ -450,6 +464,7 @@ int ptk_free(ptk_ctx* ctx, uint64_t handle) {
         else ++t;
     }
     if (ctx->image == handle) ctx->image = 0;
+    if (ctx->bound_tree && (handle == ctx->bound_tree->nodes_handle || handle == ctx->bound_tree->ids_handle)) ctx->bound_tree.reset();
     release(ctx, o);
     ctx->objects.erase(it);
     ctx->dirty = true;
@@ -1487,6 +1502,100 @@ uint64_t ptk_bvh_build(ptk_ctx* ctx, int order, int type, int n_objects, const f
     uint64_t h = ctx->next_handle++;
     ctx->objects[h] = std::move(o);
     return h;
+}
+
+int ptk_bvh_bind(ptk_ctx* ctx, uint64_t bvh, uint64_t* nodes_buffer, uint64_t* ids_buffer) {
+    if (!ctx) return PTK_E_INVALID;
+    Object* t = find(ctx, bvh, Kind::Bvh);
+    if (!t) return fail(ctx, PTK_E_INVALID, "unknown BVH handle");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int n_nodes = t->bvh->flat_node_count(), n_ids = t->bvh->flat_id_count();
+    // the sizes PTWorkDispatcher gives these buffers: nodes padded to the next multiple of 64 strictly above the
+    // count (pt_work_dispatcher.gd:13-19,163-164,723-744), ids as many as there are, 8 bytes when there are none (:756)
+    const size_t node_bytes = (size_t)(n_nodes / 64 + 1) * 64 * 32, id_bytes = n_ids > 0 ? (size_t)n_ids * 4 : 8;
+    auto make = [&](int binding, size_t nbytes) -> std::unique_ptr<Object> {
+        auto o = std::make_unique<Object>();
+        o->kind = Kind::Buffer; o->nbytes = nbytes; o->set = PTK_SET_BVH; o->binding = binding;
+        o->shadow.assign(nbytes, 0);
+        const size_t alloc = (nbytes + 255) & ~(size_t)255;
+        if (hipMalloc(&o->dev, alloc) != hipSuccess || hipMemsetAsync(o->dev, 0, alloc, ctx->stream) != hipSuccess) return nullptr;
+        return o;
+    };
+    std::unique_ptr<Object> nodes = make(0, node_bytes), ids = make(1, id_bytes);
+    if (!nodes || !ids) {
+        if (nodes) release(ctx, nodes.get());
+        if (ids) release(ctx, ids.get());
+        return fail(ctx, PTK_E_HIP, "device allocation of %zu + %zu bytes failed", node_bytes, id_bytes);
+    }
+    auto bt = std::make_unique<BoundTree>();
+    bt->bvh = t->bvh;
+    bt->state = std::make_unique<PtkRefitState>();
+    std::string err;
+    // node bytes and id table go from the builder's device buffers straight into the bound buffers; the host copies
+    // (for buffer_read-style validation and later patches) come from the same pass
+    if (!t->bvh->bind(ctx->stream, (uint8_t*)nodes->dev, n_ids > 0 ? (int32_t*)ids->dev : nullptr, nodes->shadow.data(),
+                      n_ids > 0 ? (int32_t*)ids->shadow.data() : nullptr, bt->state.get(), err)) {
+        release(ctx, nodes.get());
+        release(ctx, ids.get());
+        return fail(ctx, PTK_E_HIP, "bvh bind failed: %s", err.c_str());
+    }
+    const uint64_t hn = ctx->next_handle++, hi = ctx->next_handle++;
+    ctx->objects[hn] = std::move(nodes);
+    ctx->objects[hi] = std::move(ids);
+    ctx->bound[{PTK_SET_BVH, 0}] = hn;
+    ctx->bound[{PTK_SET_BVH, 1}] = hi;
+    bt->nodes_handle = hn;
+    bt->ids_handle = hi;
+    ctx->bound_tree = std::move(bt);
+    ctx->dirty = true;
+    if (nodes_buffer) *nodes_buffer = hn;
+    if (ids_buffer) *ids_buffer = hi;
+    return PTK_OK;
+}
+
+int ptk_bvh_refit(ptk_ctx* ctx, const ptk_refit_event* events, int n_events, int32_t* n_nodes_updated) {
+    if (!ctx) return PTK_E_INVALID;
+    if (n_nodes_updated) *n_nodes_updated = 0;
+    if (n_events < 0 || (n_events > 0 && !events)) return fail(ctx, PTK_E_INVALID, "bad event list");
+    BoundTree* bt = ctx->bound_tree.get();
+    if (!bt) return fail(ctx, PTK_E_STATE, "no tree is bound with ptk_bvh_bind (or its buffers were edited or replaced since)");
+    if (n_events == 0) return PTK_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (bt->slot_of_object.empty() && bt->state->n_ids > 0) {
+        bt->slot_of_object.reserve((size_t)bt->state->n_ids);
+        for (int i = 0; i < bt->state->n_ids; i++) bt->slot_of_object.push_back({bt->state->object_ids[i], i});
+        std::sort(bt->slot_of_object.begin(), bt->slot_of_object.end());
+    }
+    std::vector<PtkRefitEvent> ev((size_t)n_events);
+    for (int j = 0; j < n_events; j++) {
+        const int32_t id = events[j].object_id;
+        const int type = (int)((uint32_t)id >> 24);
+        ev[j].slot = -1; ev[j].mesh = -1;
+        memcpy(ev[j].v, events[j].v, 48);
+        if (type == PTK_REFIT_MESH) {
+            const int mi = id & 0x00FFFFFF;
+            for (size_t m = 0; m < bt->state->mesh_index.size(); m++) if (bt->state->mesh_index[m] == mi) ev[j].mesh = (int)m;
+            if (ev[j].mesh < 0) return fail(ctx, PTK_E_INVALID, "event %d: mesh %d is not part of the bound tree", j, mi);
+        } else {
+            auto it = std::lower_bound(bt->slot_of_object.begin(), bt->slot_of_object.end(), std::make_pair(id, (int32_t)INT32_MIN));
+            if (it == bt->slot_of_object.end() || it->first != id) return fail(ctx, PTK_E_INVALID, "event %d: object id 0x%08x is not in the bound tree", j, (unsigned)id);
+            ev[j].slot = it->second;
+        }
+    }
+    std::vector<int32_t> nodes;
+    std::vector<uint8_t> bytes;
+    std::string err;
+    if (!bt->state->refit(ctx->stream, ev, nodes, bytes, err)) { ctx->bound_tree.reset(); return fail(ctx, PTK_E_HIP, "refit failed: %s", err.c_str()); }
+    // the queued nodes reach the bound node buffer the way the plugin's own dirty-node uploads do
+    // (pt_renderer.gd:771-788): shadow copy, patched blocks, one staged transfer at the next flush
+    ctx->in_refit = true;
+    int rc = PTK_OK;
+    for (size_t k = 0; k < nodes.size() && rc == PTK_OK; k++)
+        rc = ptk_buffer_update(ctx, bt->nodes_handle, (size_t)nodes[k] * 32, bytes.data() + k * 32, 32);
+    ctx->in_refit = false;
+    if (rc != PTK_OK) return rc;
+    if (n_nodes_updated) *n_nodes_updated = (int32_t)nodes.size();
+    return PTK_OK;
 }
 
 int ptk_bvh_sizes(ptk_ctx* ctx, uint64_t bvh, int32_t* n_nodes, int32_t* n_object_ids) {

@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <initializer_list>
 
 #include "ptk_bvh.h"
 
@@ -516,9 +517,17 @@ __global__ void k_iota(int n, int* p) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) p[t] = t;
 }
-__global__ void k_gather_ids(int n, const int* perm, const int* in_ref, int* out) {
+// perm position p -> its object-id slot dest[p] (-1: a socket): the id table and, optionally, the object boxes by slot
+__global__ void k_scatter_ids(int n, const int* perm, const int* in_ref, const float* in_aabb, const int* dest, int* ids, float* obj_box) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) out[t] = in_ref[perm[t]];
+    if (t >= n || dest[t] < 0) return;
+    const int e = perm[t];
+    ids[dest[t]] = in_ref[e];
+    if (obj_box) a6_store(obj_box, dest[t], a6_load(in_aabb, e));
+}
+__global__ void k_gather_boxes(int n, const int* box_index, const float* boxes, float* out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) a6_store(out, t, a6_load(boxes, box_index[t]));
 }
 
 // ---- host side -------------------------------------------------------------------------------------------
@@ -570,7 +579,12 @@ struct BvhImpl : PtkBvh {
         return n;
     }
     int mesh_count() const override { return (int)meshes.size(); }
+    std::vector<float> mesh_xf12;      // Transform3D of each merged mesh (basis rows, origin)
     bool flatten(hipStream_t stream, uint8_t* node_bytes, int32_t* object_ids, std::string& err) override;
+    bool bind(hipStream_t stream, uint8_t* d_node_bytes, int32_t* d_object_ids, uint8_t* h_node_bytes, int32_t* h_object_ids,
+              PtkRefitState* state, std::string& err) override;
+    bool emit(hipStream_t stream, uint8_t* d_node_bytes, int32_t* d_object_ids, uint8_t* node_bytes, int32_t* object_ids,
+              PtkRefitState* state, std::string& err);
 };
 
 #define CK(expr)                                                                   \
@@ -886,8 +900,10 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
 
 }  // namespace
 
-// index_tree order + node bytes + object id table (pt_bvh_tree.gd:488-524,780-791,910-959)
-bool BvhImpl::flatten(hipStream_t st, uint8_t* node_bytes, int32_t* object_ids, std::string& err) {
+// index_tree order + node bytes + object id table (pt_bvh_tree.gd:488-524,780-791,910-959), written to
+// device and/or host memory; with `state`, also everything a later refit needs.
+bool BvhImpl::emit(hipStream_t st, uint8_t* d_node_bytes, int32_t* d_object_ids, uint8_t* node_bytes, int32_t* object_ids,
+                   PtkRefitState* state, std::string& err) {
     struct Ref { BvhImpl* tree; int node; };
     const int total = flat_node_count();
     std::vector<Ref> flat;
@@ -915,15 +931,21 @@ bool BvhImpl::flatten(hipStream_t st, uint8_t* node_bytes, int32_t* object_ids, 
         if (nd.kind == N_SOCKET) out.push_back({meshes[nd.mesh_slot].get(), 0});
         else for (int c : nd.children) out.push_back({r.tree, c});
     };
+    std::vector<int> parent_of(total, -1), depth_of(total, 0);
     {
         flat.push_back({this, 0});
         pos[0][0] = 0;
-        struct Frame { Ref r; std::vector<Ref> kids; size_t next; };
+        struct Frame { Ref r; int self; std::vector<Ref> kids; size_t next; };
         std::vector<Frame> stack;
         auto open = [&](Ref r) {
-            Frame f; f.r = r; f.next = 0;
+            Frame f; f.r = r; f.next = 0; f.self = pos[tree_slot(r.tree)][r.node];
             children_of(r, f.kids);
-            for (Ref k : f.kids) { pos[tree_slot(k.tree)][k.node] = (int)flat.size(); flat.push_back(k); }
+            for (Ref k : f.kids) {
+                const int at = (int)flat.size();
+                pos[tree_slot(k.tree)][k.node] = at;
+                if (at < total) { parent_of[at] = f.self; depth_of[at] = depth_of[f.self] + 1; }
+                flat.push_back(k);
+            }
             stack.push_back(std::move(f));
         };
         open({this, 0});
@@ -938,7 +960,8 @@ bool BvhImpl::flatten(hipStream_t st, uint8_t* node_bytes, int32_t* object_ids, 
         }
     }
     if ((int)flat.size() != total) { err = "flatten: node count mismatch"; return false; }
-    std::vector<int> box_index(total), node_id(total), xform(total);
+    std::vector<int> box_index(total), node_id(total), xform(total), first_child(total, 0), n_children(total, 0), kind(total, 0),
+        slot_first(total, 0), slot_count(total, 0), mesh_of_socket(total, -1);
     std::vector<unsigned char> empty_root(total, 0);
     std::vector<Ref> kids;
     for (int i = 0; i < total; i++) {
@@ -946,12 +969,19 @@ bool BvhImpl::flatten(hipStream_t st, uint8_t* node_bytes, int32_t* object_ids, 
         const HNode& nd = r.tree->nodes[r.node];
         int ts = tree_slot(r.tree);
         box_index[i] = box_off[ts] + r.node;
+        kind[i] = nd.kind;
         long long idx = 0, size = 0;
-        if (nd.kind == N_LEAF) { idx = -(long long)oid[ts][r.node] - 1; size = nd.obj_count - 1; }
-        else {
+        if (nd.kind == N_LEAF) {
+            idx = -(long long)oid[ts][r.node] - 1; size = nd.obj_count - 1;
+            slot_first[i] = oid[ts][r.node]; slot_count[i] = nd.obj_count;
+        } else {
             children_of(r, kids);
             if (kids.empty()) { empty_root[i] = 1; }
-            else { idx = pos[tree_slot(kids[0].tree)][kids[0].node]; size = (long long)kids.size(); }
+            else {
+                idx = pos[tree_slot(kids[0].tree)][kids[0].node]; size = (long long)kids.size();
+                first_child[i] = (int)idx; n_children[i] = (int)kids.size();
+            }
+            if (nd.kind == N_SOCKET) mesh_of_socket[i] = nd.mesh_slot;
         }
         idx ^= size << 24;
         node_id[i] = (int32_t)(uint32_t)(unsigned long long)idx;
@@ -968,28 +998,285 @@ bool BvhImpl::flatten(hipStream_t st, uint8_t* node_bytes, int32_t* object_ids, 
     CK(hipMemcpyAsync(d_id.p, node_id.data(), sizeof(int) * total, hipMemcpyHostToDevice, st));
     CK(hipMemcpyAsync(d_xf.p, xform.data(), sizeof(int) * total, hipMemcpyHostToDevice, st));
     CK(hipMemcpyAsync(d_empty.p, empty_root.data(), total, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_encode, dim3((total + 127) / 128), dim3(128), 0, st, total, d_box.p, d_id.p, d_xf.p, d_empty.p, boxes.p, out.p);
+    float* enc = d_node_bytes ? (float*)d_node_bytes : out.p;
+    hipLaunchKernelGGL(k_encode, dim3((total + 127) / 128), dim3(128), 0, st, total, d_box.p, d_id.p, d_xf.p, d_empty.p, boxes.p, enc);
     CK(hipGetLastError());
-    if (node_bytes) CK(hipMemcpyAsync(node_bytes, out.p, (size_t)total * 32, hipMemcpyDeviceToHost, st));
-    // object ids: every leaf's objects at its slot, in leaf order; a leaf's range in perm is contiguous
-    if (object_ids && io > 0) {
+    if (node_bytes) CK(hipMemcpyAsync(node_bytes, enc, (size_t)total * 32, hipMemcpyDeviceToHost, st));
+    // object ids (and, for a refit, object boxes) by id slot: every leaf's objects at its slots, in leaf order;
+    // a leaf's range in perm is contiguous, so the destination slot of every perm position is known here
+    const bool want_ids = (object_ids || d_object_ids || state) && io > 0;
+    int32_t* ids_dev = d_object_ids ? d_object_ids : d_ids.p;
+    float* obj_box_dev = nullptr;
+    if (state && io > 0) { CK(hipMalloc((void**)&state->d_obj_box, sizeof(float) * 6 * io)); obj_box_dev = state->d_obj_box; }
+    if (want_ids) {
         for (size_t t = 0; t < trees.size(); t++) {
             BvhImpl* T = trees[t];
             if (T->n_in == 0) continue;
-            DevBuf<int> gathered;
-            if (!gathered.alloc(T->n_in)) { err = "out of device memory"; return false; }
-            hipLaunchKernelGGL(k_gather_ids, dim3((T->n_in + 255) / 256), dim3(256), 0, st, T->n_in, T->perm.p, T->in_ref.p, gathered.p);
-            CK(hipGetLastError());
-            std::vector<int> h(T->n_in);
-            CK(hipMemcpyAsync(h.data(), gathered.p, sizeof(int) * T->n_in, hipMemcpyDeviceToHost, st));
-            CK(hipStreamSynchronize(st));
+            std::vector<int> dest(T->n_in, -1);
             for (int l : T->leaf_order) {
                 const HNode& nd = T->nodes[l];
-                memcpy(object_ids + oid[t][l], h.data() + nd.obj_begin, sizeof(int) * nd.obj_count);
+                for (int k = 0; k < nd.obj_count; k++) dest[nd.obj_begin + k] = oid[t][l] + k;
             }
+            DevBuf<int> d_dest;
+            if (!d_dest.alloc(T->n_in)) { err = "out of device memory"; return false; }
+            CK(hipMemcpyAsync(d_dest.p, dest.data(), sizeof(int) * T->n_in, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_scatter_ids, dim3((T->n_in + 255) / 256), dim3(256), 0, st, T->n_in, T->perm.p, T->in_ref.p, T->in_aabb.p,
+                               d_dest.p, ids_dev, obj_box_dev);
+            CK(hipGetLastError());
+            CK(hipStreamSynchronize(st));  // d_dest and dest go out of scope
         }
+        if (object_ids) CK(hipMemcpyAsync(object_ids, ids_dev, sizeof(int) * io, hipMemcpyDeviceToHost, st));
+    }
+    if (state) {
+        state->n_nodes = total; state->n_ids = io; state->n_meshes = (int)meshes.size();
+        state->parent.assign(parent_of.begin(), parent_of.end());
+        state->depth.assign(depth_of.begin(), depth_of.end());
+        state->kind.assign(kind.begin(), kind.end());
+        state->slot_leaf.assign((size_t)std::max(io, 1), -1);
+        for (int i = 0; i < total; i++)
+            for (int k = 0; k < slot_count[i]; k++) state->slot_leaf[slot_first[i] + k] = i;
+        state->mesh_socket_node.assign(meshes.size(), -1);
+        for (int i = 0; i < total; i++) if (mesh_of_socket[i] >= 0) state->mesh_socket_node[mesh_of_socket[i]] = i;
+        state->mesh_index.assign(mesh_index.begin(), mesh_index.end());
+        state->object_ids.assign((size_t)std::max(io, 0), 0);
+        if (io > 0) CK(hipMemcpyAsync(state->object_ids.data(), ids_dev, sizeof(int) * io, hipMemcpyDeviceToHost, st));
+        auto up = [&](int32_t** dst, const std::vector<int>& v) -> bool {
+            if (hipMalloc((void**)dst, sizeof(int) * std::max<size_t>(v.size(), 1)) != hipSuccess) return false;
+            return v.empty() || hipMemcpyAsync(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice, st) == hipSuccess;
+        };
+        std::vector<int> zeros(total, 0);
+        if (!up(&state->d_first_child, first_child) || !up(&state->d_n_children, n_children) || !up(&state->d_kind, kind) ||
+            !up(&state->d_slot_first, slot_first) || !up(&state->d_slot_count, slot_count) || !up(&state->d_mesh_of_socket, mesh_of_socket) ||
+            !up(&state->d_node_id, node_id) || !up(&state->d_xform, xform) || !up(&state->d_rec_off, zeros) || !up(&state->d_rec_cnt, zeros)) {
+            err = "out of device memory"; return false;
+        }
+        // raw boxes in flat order; mesh transforms by mesh slot
+        CK(hipMalloc((void**)&state->d_raw_box, sizeof(float) * 6 * total));
+        hipLaunchKernelGGL(k_gather_boxes, dim3((total + 255) / 256), dim3(256), 0, st, total, d_box.p, boxes.p, state->d_raw_box);
+        CK(hipGetLastError());
+        CK(hipMalloc((void**)&state->d_xf12, sizeof(float) * 12 * std::max<size_t>(meshes.size(), 1)));
+        if (!meshes.empty()) CK(hipMemcpyAsync(state->d_xf12, mesh_xf12.data(), sizeof(float) * 12 * meshes.size(), hipMemcpyHostToDevice, st));
     }
     CK(hipStreamSynchronize(st));
+    return true;
+}
+
+bool BvhImpl::flatten(hipStream_t st, uint8_t* node_bytes, int32_t* object_ids, std::string& err) {
+    return emit(st, nullptr, nullptr, node_bytes, object_ids, nullptr, err);
+}
+bool BvhImpl::bind(hipStream_t st, uint8_t* d_node_bytes, int32_t* d_object_ids, uint8_t* h_node_bytes, int32_t* h_object_ids,
+                   PtkRefitState* state, std::string& err) {
+    return emit(st, d_node_bytes, d_object_ids, h_node_bytes, h_object_ids, state, err);
+}
+
+// ---- refit: the reference's update_aabb chains, all edits of a call at once -------------------------------
+// BVHNode.update_aabb (pt_bvh_tree.gd:873-882): recompute the node's box (set_aabb, :856-870); if it is not
+// is_equal_approx to the old one, queue the node for upload and update the parent the same way.  PTScene calls
+// it once per moved object, in order, so a node's final box -- and whether it was ever queued -- depends on the
+// order of the edits wherever a change is smaller than the comparison's tolerance.  To keep that order and still
+// work on many edits at once, every edit j leaves a record at each node of its path to the root.  Nodes are
+// processed deepest level first, one lane per node, each lane running its node's records in edit order; the box
+// of a child "as of edit j" is the box stored in the child's last record with index <= j (records carry the box
+// forward when an edit did not reach them), or the child's box from before the call.
+namespace {
+
+DEV bool approx1(float a, float b) {  // Math::is_equal_approx(a, b), CMP_EPSILON = 1e-5
+    if (a == b) return true;
+    float tol = 0.00001f * fabsf(a);
+    if (tol < 0.00001f) tol = 0.00001f;
+    return fabsf(a - b) < tol;
+}
+DEV bool a6_equal_approx(const A6& a, const A6& b) {  // AABB::is_equal_approx: position and size, component-wise
+    return approx1(a.p[0], b.p[0]) && approx1(a.p[1], b.p[1]) && approx1(a.p[2], b.p[2]) && approx1(a.s[0], b.s[0]) &&
+           approx1(a.s[1], b.s[1]) && approx1(a.s[2], b.s[2]);
+}
+
+struct RefitArgs {
+    const int *first_child, *n_children, *kind, *slot_first, *slot_count, *mesh_of_socket, *node_id, *xform;
+    int *rec_off, *rec_cnt;
+    float *raw_box, *obj_box, *xf12;
+    const int *rec_node, *rec_j, *rec_child;  // per record
+    int* rec_changed;
+    float* rec_box;
+    const int *seg_first, *seg_count;         // per node segment
+    const int *ev_slot, *ev_mesh;
+    const float* ev_v;
+    int *out_count, *out_node;
+    float* out_bytes;
+};
+
+// box of node c as edit j sees it
+DEV A6 box_as_of(const RefitArgs& R, int c, int j) {
+    const int cnt = R.rec_cnt[c];
+    if (cnt > 0) {
+        const int off = R.rec_off[c];
+        int lo = 0, hi = cnt;  // first record with rec_j > j
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (R.rec_j[off + mid] <= j) lo = mid + 1; else hi = mid; }
+        if (lo > 0) return a6_load(R.rec_box, off + lo - 1);
+    }
+    return a6_load(R.raw_box, c);
+}
+
+__global__ void k_refit_level(RefitArgs R, int seg_begin, int n_segs) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_segs) return;
+    const int first = R.seg_first[seg_begin + t], count = R.seg_count[seg_begin + t];
+    const int node = R.rec_node[first];
+    const int kind = R.kind[node];
+    A6 cur = a6_load(R.raw_box, node);
+    for (int r = first; r < first + count; r++) {
+        const int j = R.rec_j[r];
+        const int child_rec = R.rec_child[r];
+        int changed = 0;
+        if (child_rec < 0 || R.rec_changed[child_rec]) {  // the edit itself, or an update_aabb call from the child
+            if (child_rec < 0) {
+                if (R.ev_slot[j] >= 0) a6_store(R.obj_box, R.ev_slot[j], a6_load(R.ev_v, j * 2));  // (12 floats per event: the box is the first 6)
+                else for (int k = 0; k < 12; k++) R.xf12[R.ev_mesh[j] * 12 + k] = R.ev_v[j * 12 + k];
+            }
+            A6 acc = a6_zero();  // set_aabb
+            if (kind == N_SOCKET) {
+                float tr[12];
+                const int m = R.mesh_of_socket[node];
+                for (int k = 0; k < 12; k++) tr[k] = R.xf12[m * 12 + k];
+                acc = a6_xform(tr, box_as_of(R, R.first_child[node], j));
+            } else if (kind == N_LEAF) {
+                const int b = R.slot_first[node], n = R.slot_count[node];
+                for (int k = 0; k < n; k++) acc = merge_aabb(acc, a6_load(R.obj_box, b + k));
+            } else {
+                const int b = R.first_child[node], n = R.n_children[node];
+                for (int k = 0; k < n; k++) acc = merge_aabb(acc, box_as_of(R, b + k, j));
+            }
+            changed = a6_equal_approx(acc, cur) ? 0 : 1;
+            cur = acc;
+        }
+        R.rec_changed[r] = changed;
+        a6_store(R.rec_box, r, cur);
+    }
+}
+
+// after the last level: the nodes' boxes become their final ones; queued nodes are encoded for upload
+__global__ void k_refit_commit(RefitArgs R, int n_segs) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_segs) return;
+    const int first = R.seg_first[t], count = R.seg_count[t];
+    const int node = R.rec_node[first];
+    int queued = 0;
+    for (int r = first; r < first + count; r++) queued |= R.rec_changed[r];
+    const A6 raw = a6_load(R.rec_box, first + count - 1);
+    a6_store(R.raw_box, node, raw);
+    R.rec_cnt[node] = 0;  // (leaves the lookup table clean for the next call)
+    if (!queued) return;
+    const int k = atomicAdd(R.out_count, 1);
+    R.out_node[k] = node;
+    float* o = R.out_bytes + (size_t)k * 8;
+    A6 a = a6_abs(raw);
+    const bool zero = raw.s[0] == 0.0f && raw.s[1] == 0.0f && raw.s[2] == 0.0f;
+    const float pad = zero ? 0.0f : 1e-6f;
+    o[0] = a.p[0] - pad; o[1] = a.p[1] - pad; o[2] = a.p[2] - pad;
+    o[3] = __int_as_float(R.node_id[node]);
+    o[4] = (a.p[0] + a.s[0]) + pad; o[5] = (a.p[1] + a.s[1]) + pad; o[6] = (a.p[2] + a.s[2]) + pad;
+    o[7] = __int_as_float(R.xform[node]);
+}
+
+__global__ void k_refit_index(const int* seg_first, const int* seg_count, const int* rec_node, int n_segs, int* rec_off, int* rec_cnt) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_segs) return;
+    const int node = rec_node[seg_first[t]];
+    rec_off[node] = seg_first[t];
+    rec_cnt[node] = seg_count[t];
+}
+
+}  // namespace
+
+PtkRefitState::~PtkRefitState() {
+    for (int32_t* p : {d_first_child, d_n_children, d_kind, d_slot_first, d_slot_count, d_mesh_of_socket, d_node_id, d_xform, d_rec_off, d_rec_cnt})
+        if (p) (void)hipFree(p);
+    for (float* p : {d_raw_box, d_obj_box, d_xf12})
+        if (p) (void)hipFree(p);
+}
+
+bool PtkRefitState::refit(hipStream_t st, const std::vector<PtkRefitEvent>& events, std::vector<int32_t>& nodes_out,
+                          std::vector<uint8_t>& bytes_out, std::string& err) {
+    nodes_out.clear();
+    bytes_out.clear();
+    const int n_ev = (int)events.size();
+    if (n_ev == 0) return true;
+    // records: one per (edit, node on its path), grouped by node, deepest level first, edits in order inside a node
+    struct Rec { int depth, node, j, idx_on_path; };
+    std::vector<Rec> recs;
+    recs.reserve((size_t)n_ev * 12);
+    for (int j = 0; j < n_ev; j++) {
+        int node = events[j].slot >= 0 ? slot_leaf[events[j].slot] : mesh_socket_node[events[j].mesh];
+        if (node < 0) { err = "refit: edit does not belong to the bound tree"; return false; }
+        for (int k = 0; node >= 0; node = parent[node], k++) recs.push_back({depth[node], node, j, k});
+    }
+    std::stable_sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.depth != b.depth ? a.depth > b.depth : a.node < b.node; });
+    const int R = (int)recs.size();
+    std::vector<int> rec_node(R), rec_j(R), rec_child(R, -1), seg_first, seg_count, level_first_seg, level_n_segs;
+    // the record of edit j at the child on its path: the one record of that edit one step lower on the path
+    std::vector<int> last_of_edit(n_ev, -1);
+    {
+        int cur_depth = -1;
+        for (int r = 0; r < R; r++) {
+            rec_node[r] = recs[r].node; rec_j[r] = recs[r].j;
+            if (r == 0 || recs[r].node != recs[r - 1].node || recs[r].depth != recs[r - 1].depth) {
+                if (recs[r].depth != cur_depth) { cur_depth = recs[r].depth; level_first_seg.push_back((int)seg_first.size()); level_n_segs.push_back(0); }
+                seg_first.push_back(r); seg_count.push_back(0);
+                level_n_segs.back()++;
+            }
+            seg_count.back()++;
+        }
+        // a path has one node per level and the levels are laid out deepest first, so the last record seen for
+        // an edit is the one at the path's next lower node
+        for (int r = 0; r < R; r++) {
+            rec_child[r] = recs[r].idx_on_path == 0 ? -1 : last_of_edit[recs[r].j];
+            last_of_edit[recs[r].j] = r;
+        }
+    }
+    const int S = (int)seg_first.size();
+    std::vector<int> ev_slot(n_ev), ev_mesh(n_ev);
+    std::vector<float> ev_v((size_t)n_ev * 12);
+    for (int j = 0; j < n_ev; j++) { ev_slot[j] = events[j].slot; ev_mesh[j] = events[j].mesh; memcpy(&ev_v[(size_t)j * 12], events[j].v, 48); }
+
+    DevBuf<int> d_rec_node, d_rec_j, d_rec_child, d_rec_changed, d_seg_first, d_seg_count, d_ev_slot, d_ev_mesh, d_out_count, d_out_node;
+    DevBuf<float> d_rec_box, d_ev_v, d_out_bytes;
+    if (!d_rec_node.alloc(R) || !d_rec_j.alloc(R) || !d_rec_child.alloc(R) || !d_rec_changed.alloc(R) || !d_seg_first.alloc(S) ||
+        !d_seg_count.alloc(S) || !d_ev_slot.alloc(n_ev) || !d_ev_mesh.alloc(n_ev) || !d_out_count.alloc(1) || !d_out_node.alloc(S) ||
+        !d_rec_box.alloc((size_t)R * 6) || !d_ev_v.alloc((size_t)n_ev * 12) || !d_out_bytes.alloc((size_t)S * 8)) { err = "out of device memory"; return false; }
+    CK(hipMemcpyAsync(d_rec_node.p, rec_node.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(d_rec_j.p, rec_j.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(d_rec_child.p, rec_child.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(d_seg_first.p, seg_first.data(), sizeof(int) * S, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(d_seg_count.p, seg_count.data(), sizeof(int) * S, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(d_ev_slot.p, ev_slot.data(), sizeof(int) * n_ev, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(d_ev_mesh.p, ev_mesh.data(), sizeof(int) * n_ev, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(d_ev_v.p, ev_v.data(), sizeof(float) * 12 * n_ev, hipMemcpyHostToDevice, st));
+    CK(hipMemsetAsync(d_out_count.p, 0, sizeof(int), st));
+    RefitArgs A;
+    A.first_child = d_first_child; A.n_children = d_n_children; A.kind = d_kind; A.slot_first = d_slot_first; A.slot_count = d_slot_count;
+    A.mesh_of_socket = d_mesh_of_socket; A.node_id = d_node_id; A.xform = d_xform; A.rec_off = d_rec_off; A.rec_cnt = d_rec_cnt;
+    A.raw_box = d_raw_box; A.obj_box = d_obj_box; A.xf12 = d_xf12;
+    A.rec_node = d_rec_node.p; A.rec_j = d_rec_j.p; A.rec_child = d_rec_child.p; A.rec_changed = d_rec_changed.p; A.rec_box = d_rec_box.p;
+    A.seg_first = d_seg_first.p; A.seg_count = d_seg_count.p; A.ev_slot = d_ev_slot.p; A.ev_mesh = d_ev_mesh.p; A.ev_v = d_ev_v.p;
+    A.out_count = d_out_count.p; A.out_node = d_out_node.p; A.out_bytes = d_out_bytes.p;
+    hipLaunchKernelGGL(k_refit_index, dim3((S + 127) / 128), dim3(128), 0, st, d_seg_first.p, d_seg_count.p, d_rec_node.p, S, d_rec_off, d_rec_cnt);
+    CK(hipGetLastError());
+    for (size_t l = 0; l < level_first_seg.size(); l++) {  // deepest level first
+        hipLaunchKernelGGL(k_refit_level, dim3((level_n_segs[l] + 63) / 64), dim3(64), 0, st, A, level_first_seg[l], level_n_segs[l]);
+        CK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_refit_commit, dim3((S + 127) / 128), dim3(128), 0, st, A, S);
+    CK(hipGetLastError());
+    int n_out = 0;
+    CK(hipMemcpyAsync(&n_out, d_out_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
+    if (n_out > 0) {
+        nodes_out.resize(n_out);
+        bytes_out.resize((size_t)n_out * 32);
+        CK(hipMemcpyAsync(nodes_out.data(), d_out_node.p, sizeof(int) * n_out, hipMemcpyDeviceToHost, st));
+        CK(hipMemcpyAsync(bytes_out.data(), d_out_bytes.p, (size_t)n_out * 32, hipMemcpyDeviceToHost, st));
+        CK(hipStreamSynchronize(st));
+    }
     return true;
 }
 
@@ -1008,6 +1295,7 @@ std::shared_ptr<PtkBvh> ptk_bvh_build_device(hipStream_t stream, int order, int 
         if (!mesh_trees[m] || mesh_trees[m]->mesh_count() != 0) { err = "a mesh tree must not contain mesh sockets itself"; return nullptr; }
         T->meshes.push_back(std::static_pointer_cast<BvhImpl>(mesh_trees[m]));
         T->mesh_index.push_back(mesh_indices[m]);
+        T->mesh_xf12.insert(T->mesh_xf12.end(), mesh_transforms12 + m * 12, mesh_transforms12 + m * 12 + 12);
     }
     if (!build_tree(stream, *T, aabbs6, object_ids, mesh_transforms12, err)) return nullptr;
     return T;

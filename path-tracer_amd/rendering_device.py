@@ -31,9 +31,18 @@ EXPORTS = [
     "ptk_trace_enable", "ptk_trace_read", "ptk_last_dispatch_ms", "ptk_dispatch_history_ms", "ptk_image_copy_device",
     "ptk_set_renderer", "ptk_dispatch_traverse_ms", "ptk_update_stats", "ptk_dispatch_noalloc",
     "ptk_image_read_display", "ptk_mesh_to_triangles", "ptk_set_option",
+    "ptk_bvh_bind", "ptk_bvh_refit",
 ]
 
 PTK_RENDERER_AUTO, PTK_RENDERER_SINGLE_KERNEL, PTK_RENDERER_WAVEFRONT, PTK_RENDERER_PERSISTENT = 0, 1, 2, 3
+
+PTK_REFIT_MESH = 4
+
+
+class PtkRefitEvent(C.Structure):
+    """struct ptk_refit_event of include/ptk.h."""
+    _fields_ = [("object_id", C.c_int32), ("v", C.c_float * 12)]
+
 
 class PtkMeshSurface(C.Structure):
     """struct ptk_mesh_surface of include/ptk.h."""
@@ -82,6 +91,10 @@ def load_library() -> C.CDLL:
     lib.ptk_image_read_display.argtypes = [vp, u64, vp, C.c_size_t, C.c_int]
     lib.ptk_mesh_to_triangles.restype = C.c_int
     lib.ptk_mesh_to_triangles.argtypes = [vp, C.POINTER(PtkMeshSurface), vp, C.c_int32, C.c_uint32, vp, vp, vp, i32p]
+    lib.ptk_bvh_bind.restype = C.c_int
+    lib.ptk_bvh_bind.argtypes = [vp, u64, C.POINTER(u64), C.POINTER(u64)]
+    lib.ptk_bvh_refit.restype = C.c_int
+    lib.ptk_bvh_refit.argtypes = [vp, C.POINTER(PtkRefitEvent), C.c_int, i32p]
     lib.ptk_set_option.restype = C.c_int
     lib.ptk_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.ptk_image_update.restype = C.c_int
@@ -257,6 +270,32 @@ class PtkRenderingDevice:
         ids = np.empty(max(ni.value, 1), dtype=np.int32)
         self._check(self.lib.ptk_bvh_read(self.ctx, bvh, nodes.ctypes.data, ids.ctypes.data), "ptk_bvh_read")
         return nodes.tobytes(), ids[: ni.value].copy()
+
+    def bvh_bind(self, bvh: int):
+        """Binds a built tree at (3,0) / (3,1) device to device; returns (nodes buffer, ids buffer) handles."""
+        hn, hi = C.c_uint64(0), C.c_uint64(0)
+        nn, ni = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.ptk_bvh_sizes(self.ctx, bvh, C.byref(nn), C.byref(ni)), "ptk_bvh_sizes")
+        self._check(self.lib.ptk_bvh_bind(self.ctx, bvh, C.byref(hn), C.byref(hi)), "ptk_bvh_bind")
+        self._bound_counts = (int(nn.value), int(ni.value))
+        return int(hn.value), int(hi.value)
+
+    def bvh_sizes_of_bound(self, bound):
+        """(node count, id count) of the tree most recently bound with bvh_bind."""
+        return self._bound_counts
+
+    def bvh_refit(self, object_ids, values12) -> int:
+        """update_aabb for every (object id | mesh event, new box / transform) pair, in order, on the bound tree.
+        values12: [n,12] float32 (a box uses the first six).  Returns the number of node records rewritten."""
+        ids = np.ascontiguousarray(object_ids, dtype=np.int32)
+        v = np.ascontiguousarray(values12, dtype=np.float32).reshape(-1, 12)
+        ev = (PtkRefitEvent * max(1, len(ids)))()
+        for j in range(len(ids)):
+            ev[j].object_id = int(ids[j])
+            ev[j].v = (C.c_float * 12)(*v[j].tolist())
+        n = C.c_int32(0)
+        self._check(self.lib.ptk_bvh_refit(self.ctx, ev, len(ids), C.byref(n)), "ptk_bvh_refit")
+        return int(n.value)
 
     # -- mesh ingestion ----------------------------------------------------------
     def mesh_to_triangles(self, surface: dict, transform12=None, material_index: int = 1, texture_id: int = 0):

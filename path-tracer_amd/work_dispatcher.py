@@ -206,10 +206,10 @@ def _object_lists(spheres: Sequence[sc.PTSphere], triangles, scene: sc.PTScene):
     return np.concatenate(aabbs).astype(np.float32), np.concatenate(ids).astype(np.int32)
 
 
-def create_scene_bvh(scene: sc.PTScene, builder, order: int = 8, bvh_type: Optional[int] = None):
+def build_scene_tree(scene: sc.PTScene, builder, order: int = 8, bvh_type: Optional[int] = None):
     """PTMesh._ready builds each mesh tree, then PTScene.create_BVH builds the scene tree over the
-    scene's own objects plus one socket per mesh.  Returns (node_bytes, object_ids) in GPU order, or
-    (None, None) for an empty scene."""
+    scene's own objects plus one socket per mesh.  Returns (scene tree handle, mesh tree handles), or
+    (None, []) for an empty scene; the caller releases them (builder.release)."""
     bvh_type = scene.default_bvh if bvh_type is None else bvh_type
     mesh_handles, mesh_t, mesh_i = [], [], []
     for mi, mesh in enumerate(scene.meshes):
@@ -225,8 +225,16 @@ def create_scene_bvh(scene: sc.PTScene, builder, order: int = 8, bvh_type: Optio
         mesh_i.append(mi)
     aabbs, ids = _object_lists(scene.scene_spheres, scene.scene_triangles, scene)
     if aabbs.shape[0] == 0 and not mesh_handles:
+        return None, []
+    return builder.build(order, bvh_type, aabbs, ids, mesh_handles, mesh_t, mesh_i), mesh_handles
+
+
+def create_scene_bvh(scene: sc.PTScene, builder, order: int = 8, bvh_type: Optional[int] = None):
+    """build_scene_tree, then the tree's bytes: (node_bytes, object_ids) in GPU order, or (None, None) for an
+    empty scene."""
+    h, mesh_handles = build_scene_tree(scene, builder, order, bvh_type)
+    if h is None:
         return None, None
-    h = builder.build(order, bvh_type, aabbs, ids, mesh_handles, mesh_t, mesh_i)
     try:
         return builder.read(h)
     finally:
@@ -265,8 +273,10 @@ class PackedScene:
     bvh_order: int
 
 
-def pack_scene(scene: sc.PTScene, builder, order: int = 8, bvh_type: Optional[int] = None) -> PackedScene:
-    nodes, ids = create_scene_bvh(scene, builder, order, bvh_type)
+def pack_scene(scene: sc.PTScene, builder, order: int = 8, bvh_type: Optional[int] = None, tree_bytes=None) -> PackedScene:
+    """Everything create_buffers uploads.  tree_bytes = (node_bytes, object_ids) when the tree's bytes are
+    already at hand (a tree bound on the device), else the tree is built with `builder` and read back."""
+    nodes, ids = tree_bytes if tree_bytes is not None else create_scene_bvh(scene, builder, order, bvh_type)
     return PackedScene(
         materials=create_materials_byte_array(scene),
         spheres=create_spheres_byte_array(scene),
@@ -311,8 +321,21 @@ class PTWorkDispatcher:
     def create_buffers(self, width: int, height: int, packed: Optional[PackedScene] = None, order: int = 8,
                        bvh_type: Optional[int] = None):
         assert self._scene is not None or packed is not None, "Set a scene before trying to create gpu buffers."
+        bound = None
         if packed is None:
-            packed = pack_scene(self._scene, DeviceBvhBuilder(self.rd), order, bvh_type)
+            # the tree is built on the GPU and bound where it lies (ptk_bvh_bind); its bytes are read back only
+            # to complete the host-side mirror of the buffers
+            builder = DeviceBvhBuilder(self.rd)
+            tree, mesh_trees = build_scene_tree(self._scene, builder, order, bvh_type)
+            if tree is not None:
+                bound = self.rd.bvh_bind(tree)
+                builder.release(tree, mesh_trees)  # the bound tree keeps what it needs for refits
+                n_nodes, n_ids = self.rd.bvh_sizes_of_bound(bound)
+                nodes = self.rd.buffer_get_data(bound[0], 0, n_nodes * NODE_BYTE_SIZE)
+                ids = np.frombuffer(self.rd.buffer_get_data(bound[1], 0, max(n_ids, 1) * 4), dtype=np.int32)[:n_ids]
+                packed = pack_scene(self._scene, None, order, bvh_type, tree_bytes=(nodes, ids))
+            else:
+                packed = pack_scene(self._scene, None, order, bvh_type, tree_bytes=(None, None))
         self.packed = packed
         self.image_buffer = self.rd.image_create(width, height)
         self.rids_to_free.append(self.image_buffer)
@@ -320,8 +343,12 @@ class PTWorkDispatcher:
         self.sphere_buffer = self._create_uniform(packed.spheres, OBJECT_SET_INDEX, SPHERES_BIND)
         self.plane_buffer = self._create_uniform(packed.planes, OBJECT_SET_INDEX, PLANES_BIND)
         self.triangle_buffer = self._create_uniform(packed.triangles, OBJECT_SET_INDEX, TRIANGLES_BIND)
-        self.object_id_buffer = self._create_uniform(packed.object_ids, BVH_SET_INDEX, OBJECT_ID_BIND)
-        self.bvh_buffer = self._create_uniform(packed.bvh, BVH_SET_INDEX, BVH_BIND)
+        if bound is not None:
+            self.bvh_buffer, self.object_id_buffer = bound
+            self.rids_to_free += [self.bvh_buffer, self.object_id_buffer]
+        else:
+            self.object_id_buffer = self._create_uniform(packed.object_ids, BVH_SET_INDEX, OBJECT_ID_BIND)
+            self.bvh_buffer = self._create_uniform(packed.bvh, BVH_SET_INDEX, BVH_BIND)
         # set 4 is bound but never read by the kernel; placeholders like create_triangle_buffers (:265-269)
         self.triangle_vertex_buffer = self._create_uniform(bytes(12), TRIANGLE_SET_INDEX, TRIANGLE_VERTEX_BIND)
         self.triangle_uv_buffer = self._create_uniform(bytes(12), TRIANGLE_SET_INDEX, TRIANGLE_UV_BIND)

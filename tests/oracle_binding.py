@@ -86,6 +86,8 @@ def load() -> C.CDLL:
     lib.pbo_counts.argtypes = [C.c_void_p, C.c_void_p]
     lib.pbo_flatten.restype = C.c_int
     lib.pbo_flatten.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pbo_refit.restype = C.c_int
+    lib.pbo_refit.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pbo_free.restype = None
     lib.pbo_free.argtypes = [C.c_void_p]
     lib.pbo_is_aabb_valid.restype = C.c_int
@@ -189,6 +191,18 @@ class OracleBvhBuilder:
         if rc != 0:
             raise RuntimeError(f"pbo_flatten failed: {rc}")
         return nodes.tobytes(), ids[:ni].copy()
+
+    def refit(self, t, object_ids, values12, node_bytes: bytearray):
+        """The reference's update_aabb chains, one per event in order; rewrites the queued nodes' records in
+        node_bytes (the image read() returned) and returns their flat indices in queue order."""
+        ids = np.ascontiguousarray(object_ids, dtype=np.int32)
+        v = np.ascontiguousarray(values12, dtype=np.float32).reshape(-1, 12)
+        buf = np.frombuffer(node_bytes, dtype=np.uint8)
+        queued = np.zeros(self.lib.pbo_node_count(t), dtype=np.int32)
+        n = self.lib.pbo_refit(t, len(ids), ids.ctypes.data, v.ctypes.data, buf.ctypes.data, queued.ctypes.data)
+        if n < 0:
+            raise RuntimeError("pbo_refit: unknown object or mesh")
+        return queued[:n].copy()
 
     def counts(self, t):
         c = np.zeros(4, dtype=np.int32)

@@ -48,3 +48,45 @@ for what, buf, rec, data, count in (("triangle record (80 B)", disp.triangle_buf
         print("| %s | %d | %.3f | %.3f | %.2f |" % (what, n, best_u * 1e3, best_f * 1e3, (best_u + best_f) * 1e6 / n))
 full, patched = rd.update_stats()
 print("full validations", full, "patched updates", patched)
+
+# refit: N moved triangles of the bound tree -> ptk_bvh_refit (GPU update_aabb chains) + flush at the next dispatch
+import ctypes as C
+disp.free_rids()
+rd2 = pta.PtkRenderingDevice(0)
+rd2.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
+d2 = wd.PTWorkDispatcher(rd2)
+d2.create_buffers(w, h, packed=disp.packed)
+d2.load_shader()
+tree, meshes = wd.build_scene_tree(scene, wd.DeviceBvhBuilder(rd2), 8)
+t0 = time.perf_counter()
+hn, hi = rd2.bvh_bind(tree)
+print("ptk_bvh_bind (262144 triangles, 93666 nodes): %.2f ms" % ((time.perf_counter() - t0) * 1e3))
+d2.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
+ts = scene.meshes[0].triangle_set
+boxes = ts.bvh_aabbs()
+first = scene.tri_set_first_index(ts)
+print("| refit | moved triangles | ptk_bvh_refit host ms | nodes rewritten | next dispatch call host ms |")
+print("|---|---|---|---|---|")
+for n in (1, 64, 4096):
+    picks = rng.choice(262144, size=n, replace=False)
+    ids = ((picks + first) | (3 << 24)).astype(np.int32)
+    vals = np.zeros((n, 12), np.float32)
+    best = (1e9, 0, 1e9)
+    for rep in range(4):
+        vals[:, :6] = boxes[picks]
+        vals[:, :3] += rng.normal(0, 0.05, (n, 3)).astype(np.float32)
+        ev = (pta.rendering_device.PtkRefitEvent * n)()
+        for j in range(n):
+            ev[j].object_id = int(ids[j]); ev[j].v = (C.c_float * 12)(*vals[j].tolist())
+        cnt = C.c_int32(0)
+        rd2.sync()
+        t0 = time.perf_counter()
+        rc = rd2.lib.ptk_bvh_refit(rd2.ctx, ev, n, C.byref(cnt))
+        t1 = time.perf_counter()
+        assert rc == 0
+        d2.create_compute_list(win, scene.camera, wd.sample_time(1))
+        t2 = time.perf_counter()
+        rd2.sync()
+        if t1 - t0 < best[0]:
+            best = (t1 - t0, cnt.value, t2 - t1)
+    print("| triangles of the bench scene | %d | %.3f | %d | %.3f |" % (n, best[0] * 1e3, best[1], best[2] * 1e3))
