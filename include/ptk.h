@@ -44,7 +44,11 @@ enum {
 };
 
 /* PTBVHTree.BVHType, proprietary_dataclasses/bvh_trees/pt_bvh_tree.gd:40-46 */
-enum { PTK_BVH_EMPTY = 0, PTK_BVH_X_SORTED = 1, PTK_BVH_Y_SORTED = 2, PTK_BVH_Z_SORTED = 3, PTK_BVH_XYZ_SORTED = 4 };
+enum { PTK_BVH_EMPTY = 0, PTK_BVH_X_SORTED = 1, PTK_BVH_Y_SORTED = 2, PTK_BVH_Z_SORTED = 3, PTK_BVH_XYZ_SORTED = 4,
+       /* Not a reference type: the slot the reference keeps for a surface-area-heuristic builder and leaves empty
+        * (bvh_trees/pt_bvh_sweep_sah.gd:1-21, pt_bvh_tree.gd:40-55).  Binned SAH, 8-wide nodes (order must be 8), same
+        * node bytes, id table and indexing rules as the other types, so everything downstream works unchanged. */
+       PTK_BVH_SAH = 5 };
 
 /* Replaces RenderingServer.create_local_rendering_device() /
  * get_rendering_device(), pt_work_dispatcher.gd:146-160. */

@@ -450,10 +450,176 @@ static void recursive_split_nodes(struct pbo_tree* t, Node** node_list, int n, N
     free(bins); free(halves[0].v); free(halves[1].v);
 }
 
+/* ---- binned SAH (PBO_SAH) ------------------------------------------------------------------------
+ * No counterpart in the reference (bvh_trees/pt_bvh_sweep_sah.gd is an empty class); this restates the rule
+ * of libptk's PTK_BVH_SAH builder so that its output can be compared byte for byte.  Same node format, same
+ * indexing, same leaf / socket conventions as the reference builder above; only the choice of which
+ * elements share a node differs.
+ *
+ * One wide node (up to 8 children) is made from a list by up to three rounds of binary splits: every part
+ * with more than 8 elements is split in two, parts with 8 or fewer are left alone.  A binary split looks at
+ * the elements' box centres c = (lo + hi) * 0.5 (lo = position, hi = position + size): axis = longest side
+ * of the centres' bounding box (x, then y, then z on ties), 16 equal bins along it, bin =
+ * trunc((c - cmin) * (16 / extent)) clamped to 0..15; every bin keeps a count and the bounds of its
+ * elements' boxes; the split plane after bin i (0..14) with the smallest area(L) * nL + area(R) * nR wins
+ * (first on ties; area = 2 * ((dx * dy + dy * dz) + dz * dx)); the elements keep their order on both sides.
+ * If the centres do not spread (extent <= 0, or 16 / extent not finite) or every element falls into one bin,
+ * the list is cut in the middle.  Minima and maxima use the total order of the float bit patterns
+ * (-0 < +0), so they do not depend on the order of evaluation. */
+static uint32_t ord_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+static float ord_min(float a, float b) { return ord_bits(b) < ord_bits(a) ? b : a; }
+static float ord_max(float a, float b) { return ord_bits(b) > ord_bits(a) ? b : a; }
+typedef struct { float lo[3], hi[3]; int n; } SahBin;
+static float sah_area(const float* lo, const float* hi) {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return 2.0f * ((dx * dy + dy * dz) + dz * dx);
+}
+static void elem_bounds(const Node* nd, float* lo, float* hi) {
+    lo[0] = nd->aabb.position.x; lo[1] = nd->aabb.position.y; lo[2] = nd->aabb.position.z;
+    hi[0] = nd->aabb.position.x + nd->aabb.size.x; hi[1] = nd->aabb.position.y + nd->aabb.size.y; hi[2] = nd->aabb.position.z + nd->aabb.size.z;
+}
+/* splits list[0..n) in place (stable); returns the size of the left part, or 0 when a list of 8 or fewer is
+ * better left whole (no plane with area(L) * nL + area(R) * nR < area(all) * (n - 1), or no spread) */
+static int sah_binary_split(Node** list, int n, int order) {
+    float cmin[3], cmax[3];
+    for (int i = 0; i < n; i++) {
+        float lo[3], hi[3];
+        elem_bounds(list[i], lo, hi);
+        for (int a = 0; a < 3; a++) {
+            float c = (lo[a] + hi[a]) * 0.5f;
+            cmin[a] = i ? ord_min(cmin[a], c) : c;
+            cmax[a] = i ? ord_max(cmax[a], c) : c;
+        }
+    }
+    float e[3] = {cmax[0] - cmin[0], cmax[1] - cmin[1], cmax[2] - cmin[2]};
+    int axis = 0; float m = e[0];
+    if (e[1] > m) { axis = 1; m = e[1]; }
+    if (e[2] > m) { axis = 2; m = e[2]; }
+    int n_left = -1;
+    float k = 16.0f / m;
+    unsigned char* side = (unsigned char*)malloc(n > 0 ? n : 1);
+    if (m > 0.0f && k < INFINITY) {
+        SahBin bins[16]; memset(bins, 0, sizeof bins);
+        unsigned char* bin_of = (unsigned char*)malloc(n);
+        for (int i = 0; i < n; i++) {
+            float lo[3], hi[3];
+            elem_bounds(list[i], lo, hi);
+            float q = ((lo[axis] + hi[axis]) * 0.5f - cmin[axis]) * k;
+            int b = q >= 15.0f ? 15 : (q > 0.0f ? (int)q : 0);
+            bin_of[i] = (unsigned char)b;
+            SahBin* B = &bins[b];
+            for (int a = 0; a < 3; a++) {
+                B->lo[a] = B->n ? ord_min(B->lo[a], lo[a]) : lo[a];
+                B->hi[a] = B->n ? ord_max(B->hi[a], hi[a]) : hi[a];
+            }
+            B->n++;
+        }
+        int best = -1; float best_cost = 0.0f;
+        for (int p = 0; p < 15; p++) {
+            SahBin L, R; memset(&L, 0, sizeof L); memset(&R, 0, sizeof R);
+            for (int b = 0; b < 16; b++) {
+                SahBin* D = b <= p ? &L : &R;
+                if (!bins[b].n) continue;
+                for (int a = 0; a < 3; a++) {
+                    D->lo[a] = D->n ? ord_min(D->lo[a], bins[b].lo[a]) : bins[b].lo[a];
+                    D->hi[a] = D->n ? ord_max(D->hi[a], bins[b].hi[a]) : bins[b].hi[a];
+                }
+                D->n += bins[b].n;
+            }
+            if (!L.n || !R.n) continue;
+            float cost = sah_area(L.lo, L.hi) * (float)L.n + sah_area(R.lo, R.hi) * (float)R.n;
+            if (best < 0 || cost < best_cost) { best = p; best_cost = cost; }
+        }
+        if (best >= 0 && n <= order) {  /* small enough for one leaf: split only if that pays for one more box test */
+            SahBin P; memset(&P, 0, sizeof P);
+            for (int b = 0; b < 16; b++) {
+                if (!bins[b].n) continue;
+                for (int a = 0; a < 3; a++) {
+                    P.lo[a] = P.n ? ord_min(P.lo[a], bins[b].lo[a]) : bins[b].lo[a];
+                    P.hi[a] = P.n ? ord_max(P.hi[a], bins[b].hi[a]) : bins[b].hi[a];
+                }
+                P.n += bins[b].n;
+            }
+            if (!(best_cost < sah_area(P.lo, P.hi) * (float)(n - 1))) best = -2;
+        }
+        if (best == -2) n_left = 0;
+        if (best >= 0) {
+            n_left = 0;
+            for (int i = 0; i < n; i++) { side[i] = bin_of[i] > best; if (!side[i]) n_left++; }
+        }
+        free(bin_of);
+    }
+    if (n_left < 0) {  /* no spread: cut in the middle (a list that fits one leaf stays whole) */
+        n_left = n <= order ? 0 : n / 2;
+        for (int i = 0; i < n; i++) side[i] = i >= n_left;
+    }
+    if (n_left == 0) { free(side); return 0; }
+    Node** tmp = (Node**)malloc(sizeof(Node*) * n);
+    int l = 0, r = n_left;
+    for (int i = 0; i < n; i++) { if (side[i]) tmp[r++] = list[i]; else tmp[l++] = list[i]; }
+    memcpy(list, tmp, sizeof(Node*) * n);
+    free(tmp); free(side);
+    return n_left;
+}
+/* the children of one wide node over node_list; recursion, node kinds and index_node order as in
+ * recursive_split_nodes above */
+static void sah_split_nodes(struct pbo_tree* t, Node** node_list, int n, Node* parent, NodeVec* out) {
+    const int order = t->order;
+    int mesh_count = 0;
+    for (int i = 0; i < n; i++) if (node_list[i]->is_mesh_socket) mesh_count++;
+    int begin[9], parts = 1;
+    begin[0] = 0; begin[1] = n;
+    for (int round = 0; round < 3; round++) {
+        int nb[9], np = 0;
+        for (int s = 0; s < parts; s++) {
+            int b = begin[s], e = begin[s + 1];
+            nb[np++] = b;
+            if (e - b >= 2) { int nl = sah_binary_split(node_list + b, e - b, order); if (nl > 0) nb[np++] = b + nl; }
+        }
+        nb[np] = n;
+        memcpy(begin, nb, sizeof(int) * (np + 1));
+        parts = np;
+    }
+    NodeVec new_nodes; memset(&new_nodes, 0, sizeof new_nodes);
+    for (int s = 0; s < parts && !t->error; s++) {
+        Node** nodes = node_list + begin[s];
+        int cnt = begin[s + 1] - begin[s];
+        if (cnt == 0) continue;
+        Node* new_node = node_new(t, parent);
+        new_node->is_inner = 1;
+        if (cnt > order) {
+            NodeVec sub; memset(&sub, 0, sizeof sub);
+            sah_split_nodes(t, nodes, cnt, new_node, &sub);
+            node_add_children(new_node, sub.v, sub.n);
+            free(sub.v);
+            nv_push(&new_nodes, new_node);
+            continue;
+        }
+        if (mesh_count == 0) {
+            new_node->is_inner = 0;
+            for (int i = 0; i < cnt; i++) node_add_object(new_node, nodes[i]->objects[0]);
+        } else {
+            Node* new_leaf = node_new(t, new_node);
+            new_leaf->is_inner = 0;
+            for (int i = 0; i < cnt; i++) {
+                Node* nd = nodes[i];
+                if (!nd->is_inner) node_add_object(new_leaf, nd->objects[0]);
+                else { nd->parent = new_node; node_add_child(new_node, nd); index_node(t, nd); }
+            }
+            if (node_size(new_leaf) > 0) { index_node(t, new_leaf); node_add_child(new_node, new_leaf); }
+        }
+        nv_push(&new_nodes, new_node);
+    }
+    for (int i = 0; i < new_nodes.n; i++) index_node(t, new_nodes.v[i]);
+    for (int i = 0; i < new_nodes.n; i++) nv_push(out, new_nodes.v[i]);
+    free(new_nodes.v);
+}
+
 pbo_tree* pbo_build(int order, int type, int n_objects, const float* aabbs6, const int32_t* object_ids,
                     int n_meshes, pbo_tree** mesh_trees, const float* mesh_transforms12, const int32_t* mesh_indices) {
     if (order < 2 || order > 128) return NULL;
-    if (type < PBO_X_SORTED || type > PBO_XYZ_SORTED) return NULL;
+    if (type < PBO_X_SORTED || type > PBO_SAH) return NULL;
+    if (type == PBO_SAH && order != 8) return NULL; /* the SAH rule is defined for 8-wide nodes */
     if (n_objects + n_meshes <= 0) return NULL; /* "Cannot create bvh without objects or meshes." */
     struct pbo_tree* t = (struct pbo_tree*)calloc(1, sizeof *t);
     t->order = order; t->type = type; t->n_objects = n_objects;
@@ -494,9 +660,10 @@ pbo_tree* pbo_build(int order, int type, int n_objects, const float* aabbs6, con
     if (type == PBO_X_SORTED) t->axis = 0;
     if (type == PBO_Y_SORTED) t->axis = 1;
     if (type == PBO_Z_SORTED) t->axis = 2;
-    if (type != PBO_XYZ_SORTED) { Cmp c = {t->axis}; godot_sort(&c, list, n); }
+    if (type != PBO_XYZ_SORTED && type != PBO_SAH) { Cmp c = {t->axis}; godot_sort(&c, list, n); }
     NodeVec top; memset(&top, 0, sizeof top);
-    recursive_split_nodes(t, list, n, t->root, 0, &top);
+    if (type == PBO_SAH) sah_split_nodes(t, list, n, t->root, &top);
+    else recursive_split_nodes(t, list, n, t->root, 0, &top);
     if (!t->error) node_add_children(t->root, top.v, top.n);
     free(top.v); free(list);
     /* :206-222 */

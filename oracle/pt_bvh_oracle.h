@@ -10,7 +10,8 @@ extern "C" {
 #endif
 
 /* PTBVHTree.BVHType, pt_bvh_tree.gd:40-46 */
-enum { PBO_EMPTY = 0, PBO_X_SORTED = 1, PBO_Y_SORTED = 2, PBO_Z_SORTED = 3, PBO_XYZ_SORTED = 4 };
+enum { PBO_EMPTY = 0, PBO_X_SORTED = 1, PBO_Y_SORTED = 2, PBO_Z_SORTED = 3, PBO_XYZ_SORTED = 4,
+       PBO_SAH = 5 /* not a reference type: the binned-SAH rule libptk adds (pt_bvh_sweep_sah.gd is an empty stub) */ };
 
 enum {
     PBO_OK = 0,

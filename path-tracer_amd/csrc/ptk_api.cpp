@@ -1480,7 +1480,7 @@ uint64_t ptk_bvh_build(ptk_ctx* ctx, int order, int type, int n_objects, const f
     if (!ctx) return 0;
     if (hipSetDevice(ctx->device) != hipSuccess) { fail(ctx, PTK_E_HIP, "hipSetDevice failed"); return 0; }
     if (order < 2 || order > 128) { fail(ctx, PTK_E_INVALID, "BVH order has to be >= 2 (and <= 128)"); return 0; }
-    if (type < PTK_BVH_X_SORTED || type > PTK_BVH_XYZ_SORTED) { fail(ctx, PTK_E_INVALID, "unknown BVH type %d", type); return 0; }
+    if (type < PTK_BVH_X_SORTED || type > PTK_BVH_SAH) { fail(ctx, PTK_E_INVALID, "unknown BVH type %d", type); return 0; }
     if (n_objects < 0 || n_meshes < 0 || n_objects + n_meshes <= 0) { fail(ctx, PTK_E_INVALID, "cannot create bvh without objects or meshes"); return 0; }
     if (n_objects > 0 && (!aabbs6 || !object_ids)) { fail(ctx, PTK_E_INVALID, "object arrays missing"); return 0; }
     std::vector<std::shared_ptr<PtkBvh>> subs;

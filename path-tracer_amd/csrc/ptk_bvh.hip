@@ -34,6 +34,7 @@ namespace {
 constexpr int MAX_DEPTH_LIMIT = 32;  // pt_bvh_axis_sort.gd:10
 constexpr int MAXB = 8;              // widest order the device builder bins for
 constexpr int SORT_THRESHOLD = 16;   // SortArray::INTROSORT_THRESHOLD
+constexpr int PTK_BVH_SAH_TYPE = 5;   // PTK_BVH_SAH of include/ptk.h
 
 struct A6 {
     float p[3], s[3];
@@ -530,6 +531,132 @@ __global__ void k_gather_boxes(int n, const int* box_index, const float* boxes, 
     if (t < n) a6_store(out, t, a6_load(boxes, box_index[t]));
 }
 
+// ---- binned SAH (PTK_BVH_SAH) ---------------------------------------------------------------------------
+// The reference reserves a slot for a SAH builder and leaves it empty (bvh_trees/pt_bvh_sweep_sah.gd:1-21).
+// This one emits the same node format through the same flattening, so the renderers and the refit work on
+// its trees unchanged.  Rule: a wide node's children are the parts left after up to three rounds of binary
+// splits of its list; a part of more than `order` elements is always split, a smaller one only when the best
+// plane's area(L) * nL + area(R) * nR is below area(all) * (n - 1).  A binary split bins the elements' box
+// centres c = (lo + hi) * 0.5 into 16 bins along the longest side of the centres' bounds (bin =
+// trunc((c - cmin) * (16 / extent)), clamped), keeps count and box bounds per bin, and takes the plane with
+// the smallest cost (first on ties; area = 2 * ((dx*dy + dy*dz) + dz*dx)); without spread, or with all
+// elements in one bin, a list larger than `order` is cut in the middle.  Elements keep their order on both
+// sides.  Minima and maxima are taken in the total order of the float bit patterns, so they are exact
+// whatever the order of evaluation: one wave per part reduces with LDS atomics.
+struct SahSet {
+    int begin, end;
+};
+DEV unsigned ord_enc(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+DEV float ord_dec(unsigned e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e); }
+DEV float sah_area(const float* lo, const float* hi) {
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return 2.0f * ((dx * dy + dy * dz) + dz * dx);
+}
+
+__global__ __launch_bounds__(64) void k_sah_round(const SahSet* sets, int n_sets, int* perm, int* tmp, const float* in_aabb,
+                                                  unsigned char* bin_of, int order, int* n_left_out) {
+    __shared__ unsigned s_cmin[3], s_cmax[3];
+    __shared__ unsigned s_lo[16][3], s_hi[16][3];
+    __shared__ int s_n[16];
+    __shared__ int s_best, s_nleft;
+    const int sidx = blockIdx.x;
+    if (sidx >= n_sets) return;
+    const int lane = threadIdx.x;
+    const SahSet set = sets[sidx];
+    const int n = set.end - set.begin;
+    if (lane < 3) { s_cmin[lane] = 0xFFFFFFFFu; s_cmax[lane] = 0u; }
+    if (lane < 16) { s_n[lane] = 0; for (int a = 0; a < 3; a++) { s_lo[lane][a] = 0xFFFFFFFFu; s_hi[lane][a] = 0u; } }
+    __syncthreads();
+    // centre bounds
+    {
+        unsigned mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
+        for (int i = set.begin + lane; i < set.end; i += 64) {
+            const A6 b = a6_load(in_aabb, perm[i]);
+            for (int a = 0; a < 3; a++) {
+                const unsigned e = ord_enc((b.p[a] + (b.p[a] + b.s[a])) * 0.5f);
+                mn[a] = e < mn[a] ? e : mn[a];
+                mx[a] = e > mx[a] ? e : mx[a];
+            }
+        }
+        for (int a = 0; a < 3; a++) { atomicMin(&s_cmin[a], mn[a]); atomicMax(&s_cmax[a], mx[a]); }
+    }
+    __syncthreads();
+    float cmin[3], ext[3];
+    for (int a = 0; a < 3; a++) { cmin[a] = ord_dec(s_cmin[a]); ext[a] = ord_dec(s_cmax[a]) - cmin[a]; }
+    int axis = 0;
+    float m = ext[0];
+    if (ext[1] > m) { axis = 1; m = ext[1]; }
+    if (ext[2] > m) { axis = 2; m = ext[2]; }
+    const float k = 16.0f / m;
+    const bool spread = m > 0.0f && k < __builtin_inff();
+    if (spread) {
+        for (int i = set.begin + lane; i < set.end; i += 64) {
+            const A6 b = a6_load(in_aabb, perm[i]);
+            const float q = ((b.p[axis] + (b.p[axis] + b.s[axis])) * 0.5f - cmin[axis]) * k;
+            const int bi = q >= 15.0f ? 15 : (q > 0.0f ? (int)q : 0);
+            bin_of[i] = (unsigned char)bi;
+            atomicAdd(&s_n[bi], 1);
+            for (int a = 0; a < 3; a++) { atomicMin(&s_lo[bi][a], ord_enc(b.p[a])); atomicMax(&s_hi[bi][a], ord_enc(b.p[a] + b.s[a])); }
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int best = -1, n_left = -1;
+        float best_cost = 0.0f;
+        if (spread) {
+            for (int p = 0; p < 15; p++) {
+                unsigned llo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, lhi[3] = {0u, 0u, 0u}, rlo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, rhi[3] = {0u, 0u, 0u};
+                int nl = 0, nr = 0;
+                for (int b = 0; b < 16; b++) {
+                    if (!s_n[b]) continue;
+                    if (b <= p) { nl += s_n[b]; for (int a = 0; a < 3; a++) { llo[a] = min(llo[a], s_lo[b][a]); lhi[a] = max(lhi[a], s_hi[b][a]); } }
+                    else { nr += s_n[b]; for (int a = 0; a < 3; a++) { rlo[a] = min(rlo[a], s_lo[b][a]); rhi[a] = max(rhi[a], s_hi[b][a]); } }
+                }
+                if (!nl || !nr) continue;
+                float Llo[3], Lhi[3], Rlo[3], Rhi[3];
+                for (int a = 0; a < 3; a++) { Llo[a] = ord_dec(llo[a]); Lhi[a] = ord_dec(lhi[a]); Rlo[a] = ord_dec(rlo[a]); Rhi[a] = ord_dec(rhi[a]); }
+                const float cost = sah_area(Llo, Lhi) * (float)nl + sah_area(Rlo, Rhi) * (float)nr;
+                if (best < 0 || cost < best_cost) { best = p; best_cost = cost; }
+            }
+            if (best >= 0 && n <= order) {
+                unsigned plo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, phi[3] = {0u, 0u, 0u};
+                for (int b = 0; b < 16; b++) {
+                    if (!s_n[b]) continue;
+                    for (int a = 0; a < 3; a++) { plo[a] = min(plo[a], s_lo[b][a]); phi[a] = max(phi[a], s_hi[b][a]); }
+                }
+                float Plo[3], Phi[3];
+                for (int a = 0; a < 3; a++) { Plo[a] = ord_dec(plo[a]); Phi[a] = ord_dec(phi[a]); }
+                if (!(best_cost < sah_area(Plo, Phi) * (float)(n - 1))) { best = -2; n_left = 0; }
+            }
+            if (best >= 0) { n_left = 0; for (int b = 0; b <= best; b++) n_left += s_n[b]; }
+        }
+        if (n_left < 0) { best = -1; n_left = n <= order ? 0 : n / 2; }  // no spread: cut in the middle, or leave a small list whole
+        s_best = best;
+        s_nleft = n_left;
+        n_left_out[sidx] = n_left;
+    }
+    __syncthreads();
+    const int best = s_best, n_left = s_nleft;
+    if (n_left == 0) return;
+    if (best < 0) return;  // the middle cut moves nothing
+    // stable partition: bins 0..best keep their order on the left, the others on the right
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int run_l = set.begin, run_r = set.begin + n_left;
+    for (int base = set.begin; base < set.end; base += 64) {
+        const int i = base + lane;
+        const bool in = i < set.end;
+        const bool right = in && (int)bin_of[i] > best;
+        const int v = in ? perm[i] : 0;
+        const unsigned long long mr = __ballot(right), ml = __ballot(in && !right);
+        if (in) tmp[right ? run_r + __popcll(mr & lt) : run_l + __popcll(ml & lt)] = v;
+        run_l += __popcll(ml);
+        run_r += __popcll(mr);
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = set.begin + lane; i < set.end; i += 64) perm[i] = tmp[i];
+}
+
 // ---- host side -------------------------------------------------------------------------------------------
 template <typename T>
 struct DevBuf {
@@ -672,114 +799,178 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
     DevBuf<unsigned char> bins;
     if (!keys.alloc(n_in) || !tmp.alloc(n_in) || !bins.alloc(n_in)) { err = "out of device memory"; return false; }
 
-    const int fixed_axis = (T.type == 2) ? 1 : (T.type == 3) ? 2 : 0;
-    T.nodes.clear();
-    T.nodes.emplace_back();  // root (inner)
-    std::vector<PendingCall> calls = {{0, n_in, 0}};
-    DevBuf<Call> d_calls;
-    DevBuf<CallOut> d_out;
-    DevBuf<int> d_segcount;
-    DevBuf<unsigned char> d_move;
-
-    // fixed-axis trees sort the whole list once before the recursion (pt_bvh_axis_sort.gd:193-194)
-    if (T.type != 4) {
-        Call c0 = {0, n_in};
-        CallOut o0;
-        memset(&o0, 0, sizeof o0);
-        o0.axis = fixed_axis;
-        if (!d_calls.alloc(1) || !d_out.alloc(1)) { err = "out of device memory"; return false; }
-        CK(hipMemcpyAsync(d_calls.p, &c0, sizeof c0, hipMemcpyHostToDevice, st));
-        CK(hipMemcpyAsync(d_out.p, &o0, sizeof o0, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_keys, dim3(1), dim3(64), 0, st, d_calls.p, 1, T.perm.p, T.in_aabb.p, d_out.p, keys.p);
-        CK(hipGetLastError());
-        std::vector<Seg> r = {{0, n_in, n_in > 1 ? bitlog(n_in) * 2 : 0}};
-        if (!device_sort(st, r, keys.p, T.perm.p, n_in, err)) return false;
-    }
-
-    for (int depth = 0; !calls.empty(); depth++) {
-        if (depth >= MAX_DEPTH_LIMIT + 5) { err = "too much depth (reference assert)"; return false; }
-        const int nc = (int)calls.size();
-        std::vector<Call> hc(nc);
-        for (int i = 0; i < nc; i++) hc[i] = {calls[i].begin, calls[i].end};
-        if (!d_calls.alloc(nc) || !d_out.alloc(nc) || !d_segcount.alloc(nc) || !d_move.alloc(nc)) { err = "out of device memory"; return false; }
-        CK(hipMemcpyAsync(d_calls.p, hc.data(), sizeof(Call) * nc, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_list_box, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, T.in_kind.p, T.type, fixed_axis, d_out.p);
-        CK(hipGetLastError());
-        std::vector<CallOut> ho(nc);
-        if (T.type == 4) {
-            hipLaunchKernelGGL(k_keys, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, d_out.p, keys.p);
-            CK(hipGetLastError());
-            std::vector<Seg> r(nc);
-            for (int i = 0; i < nc; i++) {
-                int len = hc[i].end - hc[i].begin;
-                r[i] = {hc[i].begin, hc[i].end, len > 1 ? bitlog(len) * 2 : 0};
-            }
-            if (!device_sort(st, r, keys.p, T.perm.p, n_in, err)) return false;
-        }
-        CK(hipMemcpyAsync(ho.data(), d_out.p, sizeof(CallOut) * nc, hipMemcpyDeviceToHost, st));
-        CK(hipStreamSynchronize(st));
-        // segment_count (pt_bvh_axis_sort.gd:276,288-296)
-        std::vector<int> segc(nc, T.order);
-        for (int i = 0; i < nc; i++) {
-            if (depth >= MAX_DEPTH_LIMIT) {
-                int mc = ho[i].mesh_count;
-                if (mc >= T.order) { /* warning only */ }
-                else if (mc > 0) segc[i] = T.order - mc;
-            }
-        }
-        CK(hipMemcpyAsync(d_segcount.p, segc.data(), sizeof(int) * nc, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_bins, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, d_segcount.p, d_out.p, bins.p);
-        CK(hipGetLastError());
-        CK(hipMemcpyAsync(ho.data(), d_out.p, sizeof(CallOut) * nc, hipMemcpyDeviceToHost, st));
-        CK(hipStreamSynchronize(st));
-        // which calls move elements: those with more than one non-empty bin (:314-325)
-        std::vector<unsigned char> mv(nc, 0);
-        for (int i = 0; i < nc; i++) {
-            if (ho[i].error) { err = "a node's centre falls outside its list's bins (reference assert 0 <= index < segment_count)"; return false; }
-            int nonempty = 0;
-            for (int b = 0; b < segc[i]; b++) nonempty += ho[i].counts[b] > 0;
-            mv[i] = nonempty > 1;
-        }
-        CK(hipMemcpyAsync(d_move.p, mv.data(), nc, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_partition, dim3(nc), dim3(64), 0, st, d_calls.p, nc, d_move.p, T.perm.p, tmp.p, d_out.p, bins.p);
-        CK(hipGetLastError());
-
-        // host: one new node per non-empty bin, in bin order (:327-371)
-        std::vector<PendingCall> next;
-        std::vector<int> fix_begin, fix_end;  // terminal bins of lists with sockets: need objects/sockets split
-        for (int i = 0; i < nc; i++) {
-            const int n = calls[i].end - calls[i].begin;
-            std::vector<std::pair<int, int>> ranges;  // [begin,end) of each bin list, in order
-            if (mv[i]) {
-                int run = calls[i].begin;
-                for (int b = 0; b < segc[i]; b++) { ranges.push_back({run, run + ho[i].counts[b]}); run += ho[i].counts[b]; }
-            } else {
-                int half = n / 2;  // a single occupied bin is cut in halves
-                ranges.push_back({calls[i].begin, calls[i].begin + half});
-                ranges.push_back({calls[i].begin + half, calls[i].end});
-            }
-            const int mesh_count = ho[i].mesh_count;
-            for (auto& r : ranges) {
-                int cnt = r.second - r.first;
-                if (cnt == 0) continue;
-                int id = (int)T.nodes.size();
-                T.nodes.emplace_back();
-                T.nodes[calls[i].parent].children.push_back(id);
-                if (cnt > T.order && depth < MAX_DEPTH_LIMIT) {
-                    T.nodes[id].recursive = true;
-                    next.push_back({r.first, r.second, id});
-                } else if (mesh_count == 0) {
-                    T.nodes[id].kind = N_LEAF;
-                    T.nodes[id].obj_begin = r.first;
-                    T.nodes[id].obj_count = cnt;
-                } else {
-                    T.nodes[id].terminal_mesh = true;
-                    T.nodes[id].obj_begin = r.first;  // resolved below
-                    T.nodes[id].obj_count = cnt;
+    if (T.type == PTK_BVH_SAH_TYPE) {
+        // ---- SAH topology: up to three rounds of binary splits per wide node, level by level ----
+        T.nodes.clear();
+        T.nodes.emplace_back();  // root (inner)
+        struct WideCall { int parent; std::vector<std::pair<int, int>> parts; };
+        std::vector<WideCall> wide = {{0, {{0, n_in}}}};
+        DevBuf<SahSet> d_sets;
+        DevBuf<int> d_nleft;
+        std::vector<int> hperm;  // only fetched when the tree has sockets (to count them per list)
+        while (!wide.empty()) {
+            for (int round = 0; round < 3; round++) {
+                std::vector<SahSet> sets;
+                std::vector<std::pair<int, int>> where;  // (wide call, part) of every set
+                for (size_t c = 0; c < wide.size(); c++)
+                    for (size_t q = 0; q < wide[c].parts.size(); q++)
+                        if (wide[c].parts[q].second - wide[c].parts[q].first >= 2) { sets.push_back({wide[c].parts[q].first, wide[c].parts[q].second}); where.push_back({(int)c, (int)q}); }
+                if (sets.empty()) break;
+                const int ns = (int)sets.size();
+                if (!d_sets.alloc(ns) || !d_nleft.alloc(ns)) { err = "out of device memory"; return false; }
+                CK(hipMemcpyAsync(d_sets.p, sets.data(), sizeof(SahSet) * ns, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_sah_round, dim3(ns), dim3(64), 0, st, d_sets.p, ns, T.perm.p, tmp.p, T.in_aabb.p, bins.p, T.order, d_nleft.p);
+                CK(hipGetLastError());
+                std::vector<int> nleft(ns);
+                CK(hipMemcpyAsync(nleft.data(), d_nleft.p, sizeof(int) * ns, hipMemcpyDeviceToHost, st));
+                CK(hipStreamSynchronize(st));
+                // split the parts (back to front inside a call, so that earlier part indices stay valid)
+                for (int k = ns - 1; k >= 0; k--) {
+                    if (nleft[k] <= 0) continue;
+                    auto& parts = wide[where[k].first].parts;
+                    const int q = where[k].second;
+                    const std::pair<int, int> whole = parts[q];
+                    parts[q] = {whole.first, whole.first + nleft[k]};
+                    parts.insert(parts.begin() + q + 1, {whole.first + nleft[k], whole.second});
                 }
             }
+            if (M > 0) { hperm.resize(n_in); CK(hipMemcpy(hperm.data(), T.perm.p, sizeof(int) * n_in, hipMemcpyDeviceToHost)); }
+            std::vector<WideCall> next;
+            for (auto& wc : wide) {
+                int mesh_count = 0;  // sockets in this call's whole list, as the reference counts them per call
+                if (M > 0) for (int i = wc.parts.front().first; i < wc.parts.back().second; i++) mesh_count += kind[hperm[i]] == 1;
+                for (auto& r : wc.parts) {
+                    const int cnt = r.second - r.first;
+                    if (cnt == 0) continue;
+                    const int id = (int)T.nodes.size();
+                    T.nodes.emplace_back();
+                    T.nodes[wc.parent].children.push_back(id);
+                    if (cnt > T.order) {
+                        T.nodes[id].recursive = true;
+                        next.push_back({id, {{r.first, r.second}}});
+                    } else if (mesh_count == 0) {
+                        T.nodes[id].kind = N_LEAF;
+                        T.nodes[id].obj_begin = r.first;
+                        T.nodes[id].obj_count = cnt;
+                    } else {
+                        T.nodes[id].terminal_mesh = true;
+                        T.nodes[id].obj_begin = r.first;
+                        T.nodes[id].obj_count = cnt;
+                    }
+                }
+            }
+            wide.swap(next);
         }
-        calls.swap(next);
+    } else {
+        const int fixed_axis = (T.type == 2) ? 1 : (T.type == 3) ? 2 : 0;
+        T.nodes.clear();
+        T.nodes.emplace_back();  // root (inner)
+        std::vector<PendingCall> calls = {{0, n_in, 0}};
+        DevBuf<Call> d_calls;
+        DevBuf<CallOut> d_out;
+        DevBuf<int> d_segcount;
+        DevBuf<unsigned char> d_move;
+
+        // fixed-axis trees sort the whole list once before the recursion (pt_bvh_axis_sort.gd:193-194)
+        if (T.type != 4) {
+            Call c0 = {0, n_in};
+            CallOut o0;
+            memset(&o0, 0, sizeof o0);
+            o0.axis = fixed_axis;
+            if (!d_calls.alloc(1) || !d_out.alloc(1)) { err = "out of device memory"; return false; }
+            CK(hipMemcpyAsync(d_calls.p, &c0, sizeof c0, hipMemcpyHostToDevice, st));
+            CK(hipMemcpyAsync(d_out.p, &o0, sizeof o0, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_keys, dim3(1), dim3(64), 0, st, d_calls.p, 1, T.perm.p, T.in_aabb.p, d_out.p, keys.p);
+            CK(hipGetLastError());
+            std::vector<Seg> r = {{0, n_in, n_in > 1 ? bitlog(n_in) * 2 : 0}};
+            if (!device_sort(st, r, keys.p, T.perm.p, n_in, err)) return false;
+        }
+
+        for (int depth = 0; !calls.empty(); depth++) {
+            if (depth >= MAX_DEPTH_LIMIT + 5) { err = "too much depth (reference assert)"; return false; }
+            const int nc = (int)calls.size();
+            std::vector<Call> hc(nc);
+            for (int i = 0; i < nc; i++) hc[i] = {calls[i].begin, calls[i].end};
+            if (!d_calls.alloc(nc) || !d_out.alloc(nc) || !d_segcount.alloc(nc) || !d_move.alloc(nc)) { err = "out of device memory"; return false; }
+            CK(hipMemcpyAsync(d_calls.p, hc.data(), sizeof(Call) * nc, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_list_box, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, T.in_kind.p, T.type, fixed_axis, d_out.p);
+            CK(hipGetLastError());
+            std::vector<CallOut> ho(nc);
+            if (T.type == 4) {
+                hipLaunchKernelGGL(k_keys, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, d_out.p, keys.p);
+                CK(hipGetLastError());
+                std::vector<Seg> r(nc);
+                for (int i = 0; i < nc; i++) {
+                    int len = hc[i].end - hc[i].begin;
+                    r[i] = {hc[i].begin, hc[i].end, len > 1 ? bitlog(len) * 2 : 0};
+                }
+                if (!device_sort(st, r, keys.p, T.perm.p, n_in, err)) return false;
+            }
+            CK(hipMemcpyAsync(ho.data(), d_out.p, sizeof(CallOut) * nc, hipMemcpyDeviceToHost, st));
+            CK(hipStreamSynchronize(st));
+            // segment_count (pt_bvh_axis_sort.gd:276,288-296)
+            std::vector<int> segc(nc, T.order);
+            for (int i = 0; i < nc; i++) {
+                if (depth >= MAX_DEPTH_LIMIT) {
+                    int mc = ho[i].mesh_count;
+                    if (mc >= T.order) { /* warning only */ }
+                    else if (mc > 0) segc[i] = T.order - mc;
+                }
+            }
+            CK(hipMemcpyAsync(d_segcount.p, segc.data(), sizeof(int) * nc, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_bins, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, d_segcount.p, d_out.p, bins.p);
+            CK(hipGetLastError());
+            CK(hipMemcpyAsync(ho.data(), d_out.p, sizeof(CallOut) * nc, hipMemcpyDeviceToHost, st));
+            CK(hipStreamSynchronize(st));
+            // which calls move elements: those with more than one non-empty bin (:314-325)
+            std::vector<unsigned char> mv(nc, 0);
+            for (int i = 0; i < nc; i++) {
+                if (ho[i].error) { err = "a node's centre falls outside its list's bins (reference assert 0 <= index < segment_count)"; return false; }
+                int nonempty = 0;
+                for (int b = 0; b < segc[i]; b++) nonempty += ho[i].counts[b] > 0;
+                mv[i] = nonempty > 1;
+            }
+            CK(hipMemcpyAsync(d_move.p, mv.data(), nc, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_partition, dim3(nc), dim3(64), 0, st, d_calls.p, nc, d_move.p, T.perm.p, tmp.p, d_out.p, bins.p);
+            CK(hipGetLastError());
+
+            // host: one new node per non-empty bin, in bin order (:327-371)
+            std::vector<PendingCall> next;
+            std::vector<int> fix_begin, fix_end;  // terminal bins of lists with sockets: need objects/sockets split
+            for (int i = 0; i < nc; i++) {
+                const int n = calls[i].end - calls[i].begin;
+                std::vector<std::pair<int, int>> ranges;  // [begin,end) of each bin list, in order
+                if (mv[i]) {
+                    int run = calls[i].begin;
+                    for (int b = 0; b < segc[i]; b++) { ranges.push_back({run, run + ho[i].counts[b]}); run += ho[i].counts[b]; }
+                } else {
+                    int half = n / 2;  // a single occupied bin is cut in halves
+                    ranges.push_back({calls[i].begin, calls[i].begin + half});
+                    ranges.push_back({calls[i].begin + half, calls[i].end});
+                }
+                const int mesh_count = ho[i].mesh_count;
+                for (auto& r : ranges) {
+                    int cnt = r.second - r.first;
+                    if (cnt == 0) continue;
+                    int id = (int)T.nodes.size();
+                    T.nodes.emplace_back();
+                    T.nodes[calls[i].parent].children.push_back(id);
+                    if (cnt > T.order && depth < MAX_DEPTH_LIMIT) {
+                        T.nodes[id].recursive = true;
+                        next.push_back({r.first, r.second, id});
+                    } else if (mesh_count == 0) {
+                        T.nodes[id].kind = N_LEAF;
+                        T.nodes[id].obj_begin = r.first;
+                        T.nodes[id].obj_count = cnt;
+                    } else {
+                        T.nodes[id].terminal_mesh = true;
+                        T.nodes[id].obj_begin = r.first;  // resolved below
+                        T.nodes[id].obj_count = cnt;
+                    }
+                }
+            }
+            calls.swap(next);
+        }
     }
     CK(hipStreamSynchronize(st));
 
@@ -1286,6 +1477,7 @@ std::shared_ptr<PtkBvh> ptk_bvh_build_device(hipStream_t stream, int order, int 
                                              const float* mesh_transforms12, const int32_t* mesh_indices,
                                              std::string& err) {
     if (order > MAXB) { err = "the device builder bins for order <= 8"; return nullptr; }
+    if (type == PTK_BVH_SAH_TYPE && order != 8) { err = "the SAH builder makes 8-wide nodes (order 8)"; return nullptr; }
     auto T = std::make_shared<BvhImpl>();
     T->order = order;
     T->type = type;

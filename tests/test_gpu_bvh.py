@@ -154,3 +154,80 @@ def test_scene_tree_outlives_its_mesh_handles(pta, rd):
     gpu_nodes, gpu_ids = rd.bvh_read(tree)  # and again: reading is repeatable
     _check("second read", cpu_nodes, cpu_ids, gpu_nodes, gpu_ids)
     rd.free_rid(tree)
+
+
+# ---- PTK_BVH_SAH: the builder type the reference leaves as an empty stub (pt_bvh_sweep_sah.gd) ------------------
+def _sah_both(pta, rd, scene):
+    for m in scene.meshes:
+        m.bvh_type = 5
+    return _both(pta, rd, scene, 8, 5)
+
+
+@pytest.mark.parametrize("name", ["sphere_scene1", "benchmark_random_scene", "fake_cornell_box", "sphere_scene3", "dragon_test",
+                                  "test_scene_bvh_a", "test_scene_bvh_b"])
+def test_sah_fixture_scenes(pta, rd, golden_dir, name):
+    """Binned-SAH trees: node bytes and id table bit-exact against the CPU restatement of the same rule."""
+    _check(f"{name}/sah", *_sah_both(pta, rd, pta.scenes.load_fixture_scene(name, golden_dir)))
+
+
+def test_sah_tie_heavy_grid_and_identical_objects(pta, rd):
+    sc, gm = pta.scene, pta.godot_math
+    scene = sc.PTScene(default_bvh=5)
+    mesh = sc.PTMesh(bvh_type=5)
+    mesh.scene = scene
+    mesh.triangle_set = sc.PTTriangleSet(vertices=_grid_triangles(40, 5))
+    scene.add_mesh(mesh)
+    for _ in range(100):  # no spread at all: lists are cut in the middle
+        scene.add_object(sc.PTSphere(transform=gm.Transform3D(origin=(1.0, 2.0, 3.0)), radius=0.25))
+    _check("grid+identical/sah", *_sah_both(pta, rd, scene))
+
+
+def test_sah_atrium_full_size_and_many_meshes(pta, rd):
+    _check("atrium262k/sah", *_sah_both(pta, rd, pta.scenes.atrium_scene(262144, seed=7)))
+    sc, gm = pta.scene, pta.godot_math
+    rng = np.random.default_rng(11)
+    scene = sc.PTScene(default_bvh=5)
+    for i in range(5):
+        scene.add_object(sc.PTSphere(transform=gm.Transform3D(origin=tuple(rng.uniform(-6, 6, 3))), radius=float(rng.uniform(0.2, 1.0))))
+    for m in range(11):
+        mesh = sc.PTMesh(transform=gm.Transform3D.looking_at(tuple(rng.uniform(-8, 8, 3)), tuple(rng.uniform(-1, 1, 3))), bvh_type=5)
+        mesh.scene = scene
+        base = rng.uniform(-1, 1, (300, 1, 3)).astype(np.float32)
+        mesh.triangle_set = sc.PTTriangleSet(vertices=(base + rng.normal(0, 0.1, (300, 3, 3))).astype(np.float32))
+        scene.add_mesh(mesh)
+    _check("meshes/sah", *_sah_both(pta, rd, scene))
+    with pytest.raises(pta.PtkError):
+        rd.bvh_build(4, 5, np.ones((20, 6), np.float32), np.arange(20, dtype=np.int32))  # SAH is defined for order 8
+
+
+def test_sah_tree_renders_the_same_image_with_less_work(pta, golden_dir):
+    """The renderers run unchanged over a SAH tree: same image as the oracle over the same bytes (all schedules),
+    and fewer box + object tests per ray than the reference's X-sorted tree on the random-spheres scene."""
+    from test_gpu_parity import _compare_image
+
+    wd = pta.work_dispatcher
+    scene = pta.scenes.load_fixture_scene("benchmark_random_scene", golden_dir)
+    w, h = 320, 184
+    work = {}
+    for typ in (1, 5):
+        dev = pta.PtkRenderingDevice(0)
+        try:
+            disp = wd.PTWorkDispatcher(dev)
+            disp.set_scene(scene)
+            disp.create_buffers(w, h, order=8, bvh_type=typ)  # built and bound on the GPU
+            disp.load_shader()
+            win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=8, max_refraction_bounces=4)
+            cpu = np.zeros((h, w, 4), np.float32)
+            out = ob.render(disp.packed, wd.push_constant_bytes(scene.camera, win, wd.sample_time(1)), cpu, w // 8, h // 8)
+            for r in (1, 2, 3):
+                dev.set_renderer(r)
+                dev.texture_update(disp.image_buffer, np.zeros((h, w, 4), np.float32))
+                disp.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
+                _compare_image(f"type{typ} renderer{r}", dev.texture_get_data(disp.image_buffer), cpu)
+            t = dict(zip(ob.STAT_NAMES, out["totals"].tolist()))
+            work[typ] = (t["box_tests"] + t["obj_tests"]) / t["rays"]
+            disp.free_rids()
+        finally:
+            dev.close()
+    print("box + object tests per ray: X-sorted %.1f, SAH %.1f" % (work[1], work[5]))
+    assert work[5] < 0.7 * work[1]

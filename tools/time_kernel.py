@@ -17,7 +17,14 @@ rd = pta.PtkRenderingDevice(0)
 rd.set_renderer(int(os.environ.get("PTK_RENDERER", "0")))
 disp = wd.PTWorkDispatcher(rd)
 disp.set_scene(scene)
-disp.create_buffers(w, h, order=8)
+bvh_type = int(os.environ["PTK_BVH_TYPE"]) if os.environ.get("PTK_BVH_TYPE") else None  # 5 = binned SAH
+if bvh_type:
+    for m in scene.meshes:
+        m.bvh_type = bvh_type
+import time as _t
+_t0 = _t.perf_counter()
+disp.create_buffers(w, h, order=8, bvh_type=bvh_type)
+print("create_buffers (BVH build + bind + uploads) %.1f ms, %d nodes" % ((_t.perf_counter() - _t0) * 1e3, len(disp.packed.bvh) // 32))
 disp.load_shader(refraction_mode=2, use_emission=False, early_t_break=False)
 win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=8, max_refraction_bounces=4)
 for k in range(8):
