@@ -221,8 +221,12 @@ PTK_DEV void hit_object(const PtkParams& P, Lane& L, Ray& ray, Hit& h, int objec
 }
 
 // ---- traversal stack ------------------------------------------------------------
+// LDS pointers are kept in the LDS address space, so that reads through them are LDS instructions (a generic
+// pointer that may be either LDS or global memory turns into flat loads, which take the vector-memory path)
+typedef float PtkV4 __attribute__((ext_vector_type(4)));
+typedef const PtkV4 __attribute__((address_space(3))) * PtkLdsBlocks;
 struct Stack {
-    const float4* top = nullptr;  // LDS copy of node blocks [0, n_top), PTK_TOP_BLOCK_STRIDE bytes apart (traversal kernel only)
+    PtkLdsBlocks top = nullptr;   // LDS copy of node blocks [0, n_top), PTK_TOP_BLOCK_STRIDE bytes apart (traversal kernel only)
     uint32_t n_top = 0;
     int* lds;        // this wave's LDS window, [entry][lane]
     int* spill;      // global column of this lane, stride = spill_stride ints
@@ -669,9 +673,9 @@ PTK_DEV bool trav_inner(const PtkParams& P, const Stack& S, Trav& T) {
     float4 q[14];
     if (blk < S.n_top) {
         // the top of the tree is resident in LDS: no trip through the vector cache for these
-        const float4* lb = S.top + (size_t)blk * (PTK_TOP_BLOCK_STRIDE / 16);
+        PtkLdsBlocks lb = S.top + blk * (PTK_TOP_BLOCK_STRIDE / 16);
 #pragma unroll
-        for (int k = 0; k < 14; k++) q[k] = lb[k];
+        for (int k = 0; k < 14; k++) { const PtkV4 v = lb[k]; q[k] = make_float4(v.x, v.y, v.z, v.w); }
     } else {
         const float4* __restrict__ cb = W.blocks + (size_t)blk * 16;
 #pragma unroll

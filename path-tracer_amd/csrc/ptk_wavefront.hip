@@ -128,7 +128,7 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
         __syncthreads();  // the only workgroup-wide step: from here on every wave runs on its own
     }
     Stack S;
-    S.top = (const float4*)lds_all; S.n_top = W.n_top;
+    S.top = (PtkLdsBlocks)lds_all; S.n_top = W.n_top;
     S.lds = lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + wave * (P.lds_cap + 1) * 64;
     S.lane = lane; S.lds_cap = P.lds_cap; S.spill_stride = P.spill_stride;
     S.spill = P.spill ? P.spill + ((size_t)blockIdx.x * PTK_WF_WG_WAVES + wave) * 64 + lane : nullptr;
