@@ -142,7 +142,7 @@ struct CallOut {
 // .abs().grow(1e-6) (:277); also counts mesh sockets and picks the axis (:279-280).
 __global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls, const int* perm, const float* in_aabb,
                                                  const int* in_kind, int type, int fixed_axis, CallOut* out) {
-    __shared__ float tr[6][64];
+    __shared__ __align__(16) float tr[6][64];
     int c = blockIdx.x;
     if (c >= n_calls) return;
     int lane = threadIdx.x;
@@ -150,12 +150,24 @@ __global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls,
     A6 acc = a6_zero();
     bool acc_valid = false;  // a6_valid(acc), kept alongside (uniform over the wave)
     int meshes = 0;
+    // The boxes are gathered through perm (two dependent loads); the batch after the current one is already in
+    // flight while the chain below runs, and the indices of the one after that.
+    A6 next_box = a6_zero();
+    int next_kind = 0, next_id = -1;
+    {
+        const int i = call.begin + lane;
+        if (i < call.end) { const int id = perm[i]; next_box = a6_load(in_aabb, id); next_kind = in_kind[id]; }
+        if (i + 64 < call.end) next_id = perm[i + 64];
+    }
     for (int base = call.begin; base < call.end; base += 64) {
         int i = base + lane;
         bool in = i < call.end;
-        A6 mine = a6_zero();
-        int kind = 0;
-        if (in) { int id = perm[i]; mine = a6_load(in_aabb, id); kind = in_kind[id]; }
+        const A6 mine = next_box;
+        const int kind = next_kind;
+        next_box = a6_zero();
+        next_kind = 0;
+        if (next_id >= 0) { next_box = a6_load(in_aabb, next_id); next_kind = in_kind[next_id]; }
+        next_id = i + 128 < call.end ? perm[i + 128] : -1;
         meshes += __popcll(__ballot(in && kind == 1));
         const int cnt = min(64, call.end - base);
         const unsigned long long vmask = __ballot(in && a6_valid(mine));
@@ -174,34 +186,50 @@ __global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls,
         // s' = max(e1, bp + bs) - p'  per axis, in list order (the float merge is not associative, so the
         // order is kept; what is saved is the validity test of both operands inside every step).  A valid
         // box has s >= 0 and stays so; it can only turn invalid by becoming non-finite (which then sticks
-        // until the end of the batch) or by all three sizes rounding to zero (checked at every step).
+        // until the end of the batch) or by all three sizes rounding to zero at one step.
         // If either happened, the batch is redone with the full merge.
         float e2x = mine.p[0] + mine.s[0], e2y = mine.p[1] + mine.s[1], e2z = mine.p[2] + mine.s[2];
         float px = acc.p[0], py = acc.p[1], pz = acc.p[2], sx = acc.s[0], sy = acc.s[1], sz = acc.s[2];
         bool collapsed = false;
+        bool fast = false;
+        float mx = mine.p[0], my = mine.p[1], mz = mine.p[2];
         if (j0 == 0 && vmask == ~0ull) {
-            // a full batch of valid boxes: the three axes are independent chains, so lanes 0..2 run one
-            // axis each over the batch transposed through LDS (7 operations per element and axis)
-            tr[0][lane] = mine.p[0]; tr[1][lane] = mine.p[1]; tr[2][lane] = mine.p[2];
-            tr[3][lane] = e2x; tr[4][lane] = e2y; tr[5][lane] = e2z;
-            __syncthreads();
-            const int a = lane < 3 ? lane : 0;
-            float p = a == 0 ? px : (a == 1 ? py : pz);
-            float sa = a == 0 ? sx : (a == 1 ? sy : sz);
-            float smin = __builtin_inff();
-#pragma unroll
-            for (int j = 0; j < 64; j++) {
-                const float bp = tr[a][j], fe = tr[3 + a][j];
-                const float e1 = p + sa;
-                p = p < bp ? p : bp;
-                sa = (e1 > fe ? e1 : fe) - p;
-                smin = sa < smin ? sa : smin;
+            // A full batch of valid boxes.  The position after element j is the running "p < bp ? p : bp" over the
+            // elements up to j, an associative pick (smallest value, the later one among equals) that does not
+            // depend on the sizes: all 64 are found at once by a scan.
+            for (int o = 1; o < 64; o <<= 1) {
+                const float ux = __shfl_up(mx, o), uy = __shfl_up(my, o), uz = __shfl_up(mz, o);
+                if (lane >= o) { mx = ux < mx ? ux : mx; my = uy < my ? uy : my; mz = uz < mz ? uz : mz; }
             }
-            __syncthreads();
-            px = rdlane(p, 0); py = rdlane(p, 1); pz = rdlane(p, 2);
+            mx = px < mx ? px : mx; my = py < my ? py : my; mz = pz < mz ? pz : mz;
+            // A size is max(e1, far end) - position with far end >= position, so it is zero only where an
+            // element's far end equals the position after it; all three sizes zero at one element (the box turning
+            // invalid) needs that on all three axes.  Batches where this can happen take the general loop below.
+            fast = !__any(e2x == mx && e2y == my && e2z == mz);
+        }
+        if (fast) {
+            // what is left is the chain of sizes, three dependent operations per element and axis:
+            // lanes 0..2 run one axis each over the batch transposed through LDS
+            tr[0][lane] = mx; tr[1][lane] = my; tr[2][lane] = mz;
+            tr[3][lane] = e2x; tr[4][lane] = e2y; tr[5][lane] = e2z;
+            __builtin_amdgcn_wave_barrier();  // one wave: its LDS accesses execute in program order
+            const int a = lane < 3 ? lane : 0;
+            float pprev = a == 0 ? px : (a == 1 ? py : pz);
+            float sa = a == 0 ? sx : (a == 1 ? sy : sz);
+            const float4* pos4 = reinterpret_cast<const float4*>(&tr[a][0]);
+            const float4* far4 = reinterpret_cast<const float4*>(&tr[3 + a][0]);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const float4 pj = pos4[q], fe = far4[q];
+                float e1;
+                e1 = pprev + sa; sa = (e1 > fe.x ? e1 : fe.x) - pj.x; pprev = pj.x;
+                e1 = pprev + sa; sa = (e1 > fe.y ? e1 : fe.y) - pj.y; pprev = pj.y;
+                e1 = pprev + sa; sa = (e1 > fe.z ? e1 : fe.z) - pj.z; pprev = pj.z;
+                e1 = pprev + sa; sa = (e1 > fe.w ? e1 : fe.w) - pj.w; pprev = pj.w;
+            }
+            __builtin_amdgcn_wave_barrier();
+            px = rdlane(mx, 63); py = rdlane(my, 63); pz = rdlane(mz, 63);
             sx = rdlane(sa, 0); sy = rdlane(sa, 1); sz = rdlane(sa, 2);
-            // all three sizes zero at one step needs every axis to have reached zero at some step
-            collapsed = rdlane(smin, 0) == 0.0f && rdlane(smin, 1) == 0.0f && rdlane(smin, 2) == 0.0f;
         } else {
             for (int j = j0; j < cnt; j++) {
                 if (!((vmask >> j) & 1ull)) continue;
@@ -241,40 +269,57 @@ __global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls,
 }
 
 // sort key of every element of a call: centre of its box on the call's axis (pt_bvh_axis_sort.gd:180-181)
-__global__ __launch_bounds__(64) void k_keys(const Call* calls, int n_calls, const int* perm, const float* in_aabb,
-                                             const CallOut* co, float* keys) {
+__global__ __launch_bounds__(256) void k_keys(const Call* calls, int n_calls, const int* perm, const float* in_aabb,
+                                              const CallOut* co, float* keys) {
     int c = blockIdx.x;
     if (c >= n_calls) return;
     Call call = calls[c];
     int axis = co[c].axis;
-    for (int i = call.begin + threadIdx.x; i < call.end; i += 64) {
+    for (int i = call.begin + blockIdx.y * 256 + threadIdx.x; i < call.end; i += gridDim.y * 256) {
         A6 a = a6_load(in_aabb, perm[i]);
         keys[i] = a6_center(a, axis);
     }
 }
 
-// bin index of every element (pt_bvh_axis_sort.gd:304-309) + per-bin counts
-__global__ __launch_bounds__(64) void k_bins(const Call* calls, int n_calls, const int* perm, const float* in_aabb,
-                                             const int* seg_count, CallOut* co, unsigned char* bins) {
+// segment_count of a call (pt_bvh_axis_sort.gd:276,288-296): the order, less the sockets of a list at the depth limit
+DEV int call_segment_count(int order, bool at_depth_limit, int mesh_count) {
+    if (at_depth_limit && mesh_count > 0 && mesh_count < order) return order - mesh_count;
+    return order;
+}
+
+// k_bins and k_partition cut a call's range into ny * 4 contiguous slices, one per wave of a (call, y) block of
+// 256 threads; a slice holds a multiple of 64 elements.
+DEV int call_slice_len(int len, int ny) {
+    const int n_slices = ny * 4;
+    return (((len + n_slices - 1) / n_slices) + 63) & ~63;
+}
+
+// bin index of every element (pt_bvh_axis_sort.gd:304-309); per-bin counts of every slice (slice_counts) and of
+// the call (added to co[c].counts, which k_list_box left at zero)
+__global__ __launch_bounds__(256) void k_bins(const Call* calls, int n_calls, const int* perm, const float* in_aabb,
+                                              int order, int at_depth_limit, CallOut* co, unsigned char* bins, int* slice_counts) {
     int c = blockIdx.x;
     if (c >= n_calls) return;
-    int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     Call call = calls[c];
-    CallOut o = co[c];
-    int axis = o.axis;
-    int segs = seg_count[c];
+    const int slice = blockIdx.y * 4 + (threadIdx.x >> 6), slice_len = call_slice_len(call.end - call.begin, gridDim.y);
+    const int begin = call.begin + slice * slice_len, end = min(call.end, begin + slice_len);
+    if (begin >= call.end) return;
+    const int axis = co[c].axis;
+    const float lo = co[c].aabb[axis], size = co[c].aabb[3 + axis];
+    const int segs = call_segment_count(order, at_depth_limit != 0, co[c].mesh_count);
     // (size / segment_count)[axis]: float32 divide, widened to double
-    double segment = (double)(o.aabb[3 + axis] / (float)segs);
+    double segment = (double)(size / (float)segs);
     int counts[MAXB];
     for (int b = 0; b < MAXB; b++) counts[b] = 0;
     int err = 0;
-    for (int base = call.begin; base < call.end; base += 64) {
+    for (int base = begin; base < end; base += 64) {
         int i = base + lane;
-        bool in = i < call.end;
+        bool in = i < end;
         int bin = -1;
         if (in) {
             A6 a = a6_load(in_aabb, perm[i]);
-            float rel = a6_center(a, axis) - o.aabb[axis];
+            float rel = a6_center(a, axis) - lo;
             double q = floor((double)rel / segment);
             if (!(q >= 0.0 && q < (double)segs)) { err = 1; q = 0.0; }
             bin = (int)q;
@@ -284,25 +329,43 @@ __global__ __launch_bounds__(64) void k_bins(const Call* calls, int n_calls, con
     }
     err = __any(err);
     if (lane == 0) {
-        for (int b = 0; b < MAXB; b++) co[c].counts[b] = counts[b];
-        co[c].error = err;
+        int* mine = slice_counts + ((size_t)c * gridDim.y * 4 + slice) * MAXB;
+        for (int b = 0; b < MAXB; b++) { mine[b] = counts[b]; if (counts[b]) atomicAdd(&co[c].counts[b], counts[b]); }
+        if (err) atomicOr(&co[c].error, 1);
     }
 }
 
-// stable partition of a call's range by bin (bins keep list order); two passes through tmp
-__global__ __launch_bounds__(64) void k_partition(const Call* calls, int n_calls, const unsigned char* do_move, int* perm,
-                                                  int* tmp, const CallOut* co, const unsigned char* bins) {
+// stable partition of a call's range by bin (bins keep list order), for calls with more than one occupied bin
+// (pt_bvh_axis_sort.gd:314-325): every wave places its slice into tmp behind the earlier slices' elements of the
+// same bin; k_partition_copy brings the result back.
+__global__ __launch_bounds__(256) void k_partition(const Call* calls, int n_calls, const int* perm, int* tmp, const CallOut* co,
+                                                   const unsigned char* bins, const int* slice_counts) {
     int c = blockIdx.x;
-    if (c >= n_calls || !do_move[c]) return;
-    int lane = threadIdx.x;
+    if (c >= n_calls) return;
+    const int lane = threadIdx.x & 63;
     Call call = calls[c];
+    const int slice = blockIdx.y * 4 + (threadIdx.x >> 6), slice_len = call_slice_len(call.end - call.begin, gridDim.y);
+    const int begin = call.begin + slice * slice_len, end = min(call.end, begin + slice_len);
+    if (begin >= call.end) return;
     int offs[MAXB];
-    int run = call.begin;
-    for (int b = 0; b < MAXB; b++) { offs[b] = run; run += co[c].counts[b]; }
+    int run = call.begin, occupied = 0;
+    for (int b = 0; b < MAXB; b++) { offs[b] = run; run += co[c].counts[b]; occupied += co[c].counts[b] > 0; }
+    if (occupied <= 1) return;
+    // elements of each bin in the slices before this one
+    const int* all = slice_counts + (size_t)c * gridDim.y * 4 * MAXB;
+    int before[MAXB];
+    for (int b = 0; b < MAXB; b++) before[b] = 0;
+    for (int w = lane; w < slice; w += 64)
+        for (int b = 0; b < MAXB; b++) before[b] += all[w * MAXB + b];
+    for (int b = 0; b < MAXB; b++) {
+        int v = before[b];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        offs[b] += v;
+    }
     unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int base = call.begin; base < call.end; base += 64) {
+    for (int base = begin; base < end; base += 64) {
         int i = base + lane;
-        bool in = i < call.end;
+        bool in = i < end;
         int bin = in ? (int)bins[i] : -1;
         int v = in ? perm[i] : 0;
         for (int b = 0; b < MAXB; b++) {
@@ -311,8 +374,15 @@ __global__ __launch_bounds__(64) void k_partition(const Call* calls, int n_calls
             offs[b] += __popcll(m);
         }
     }
-    __threadfence_block();
-    for (int i = call.begin + lane; i < call.end; i += 64) perm[i] = tmp[i];
+}
+__global__ __launch_bounds__(256) void k_partition_copy(const Call* calls, int n_calls, int* perm, const int* tmp, const CallOut* co) {
+    int c = blockIdx.x;
+    if (c >= n_calls) return;
+    Call call = calls[c];
+    int occupied = 0;
+    for (int b = 0; b < MAXB; b++) occupied += co[c].counts[b] > 0;
+    if (occupied <= 1) return;
+    for (int i = call.begin + blockIdx.y * 256 + threadIdx.x; i < call.end; i += gridDim.y * 256) perm[i] = tmp[i];
 }
 
 // ---- exact emulation of Godot's SortArray on (key descending, payload) ------------------------------
@@ -372,78 +442,249 @@ DEV void heap_sort(float* k, int* v, int first, int last) {
     }
 }
 
-// One quicksort level: one wave per segment replays SortArray::partitioner and queues the two parts.
-__global__ __launch_bounds__(64) void k_sort_level(const Seg* segs, int n_segs, float* keys, int* vals, Seg* next,
-                                                   int* next_count, Seg* finals, int* final_count) {
+constexpr int SORT_BIG = 1024;     // segments longer than this are partitioned by a whole 1024-thread workgroup
+constexpr int SORT_RANK_MAX = 8192;  // longest segment whose heapsort fallback is done by counting
+constexpr int SORT_MAX_LEVELS = 72;  // more than the largest depth budget, 2 * bitlog(2^31)
+
+// where the two parts of a partitioned segment go: the queue of the next level (by size) or the final insertion pass
+DEV void sort_emit(Seg part, Seg* next, int* next_count, Seg* next_big, int* big_count, Seg* finals, int* final_count) {
+    const int len = part.last - part.first;
+    if (len > SORT_BIG) next_big[atomicAdd(big_count, 1)] = part;
+    else if (len > SORT_THRESHOLD) next[atomicAdd(next_count, 1)] = part;
+    else if (len > 1) finals[atomicAdd(final_count, 1)] = part;
+}
+
+// Sorts one segment of at most SORT_BIG elements down to pieces of at most SORT_THRESHOLD: one wave copies it to
+// LDS and replays SortArray::introsort over it with an explicit stack (the two parts of a partition are independent,
+// so the order in which they are taken does not matter), then writes it back.  A partition lowers the depth budget by
+// one and a segment with no budget left is heap-sorted without children, so the stack never holds more than
+// budget + 1 entries.  The partition is the one of k_sort_level_big below, with the stop lists in LDS too.  The
+// pieces of at most SORT_THRESHOLD elements get their share of the final insertion pass before the copy back.
+__global__ __launch_bounds__(64) void k_sort_small(const Seg* segs, const int* n_segs, float* keys, int* vals) {
+    __shared__ Seg stack[72];
+    __shared__ float sk[SORT_BIG];
+    __shared__ int sv[SORT_BIG];
+    __shared__ unsigned short stops_l[SORT_BIG], stops_r[SORT_BIG];
+    __shared__ unsigned int done[SORT_BIG / 2];  // finished pieces of 2..SORT_THRESHOLD elements: first | length << 16
     int s = blockIdx.x;
-    if (s >= n_segs) return;
+    if (s >= *n_segs) return;
     const int lane = threadIdx.x;
-    Seg seg = segs[s];
+    int n_done = 0;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const Seg whole = segs[s];
+    const int base = whole.first, n_whole = whole.last - whole.first;  // positions below are relative to base
+    for (int i = lane; i < n_whole; i += 64) { sk[i] = keys[base + i]; sv[i] = vals[base + i]; }
+    if (lane == 0) { Seg r = {0, n_whole, whole.depth}; stack[0] = r; }
+    int sp = 1;
+    while (sp > 0) {
+        __builtin_amdgcn_wave_barrier();  // one wave: its LDS accesses execute in program order
+        const Seg seg = stack[--sp];
+        __builtin_amdgcn_wave_barrier();
+        const int first = seg.first, last = seg.last;
+        const int n = last - first;
+        if (seg.depth == 0) {
+            // SortArray::partial_sort over the whole segment, a heapsort.  With no two keys equal (and none a NaN) its
+            // result is simply the sorted order, found here by counting, for every element, the elements before it;
+            // otherwise one lane runs the heapsort itself, whose order among equal keys is its own.
+            float rk[SORT_BIG / 64];
+            int rv[SORT_BIG / 64], rank[SORT_BIG / 64];
+            bool plain = true;
+#pragma unroll
+            for (int t = 0; t < SORT_BIG / 64; t++) {
+                const int i = first + lane + 64 * t;
+                rank[t] = -1;
+                if (i < last) {
+                    rk[t] = sk[i]; rv[t] = sv[i];
+                    int before = 0, same = 0;
+                    for (int j = first; j < last; j++) { const float kj = sk[j]; before += cmp_less(kj, rk[t]) ? 1 : 0; same += kj == rk[t] ? 1 : 0; }
+                    rank[t] = before;
+                    plain = plain && same == 1;
+                }
+            }
+            plain = !__any(!plain);
+            __builtin_amdgcn_wave_barrier();
+            if (plain) {
+#pragma unroll
+                for (int t = 0; t < SORT_BIG / 64; t++) if (rank[t] >= 0) { sk[first + rank[t]] = rk[t]; sv[first + rank[t]] = rv[t]; }
+            } else if (lane == 0) {
+                heap_sort(sk, sv, first, last);
+            }
+            continue;  // fully sorted; no final insertion pass needed
+        }
+        const float P = median_of_3(sk[first], sk[first + (last - first) / 2], sk[last - 1]);
+        int nl = 0, nr = 0;
+        for (int chunk = 0; chunk < n; chunk += 64) {
+            const int off = chunk + lane;
+            const bool in = off < n;
+            const bool stop_l = in && !cmp_less(sk[first + off], P);
+            const bool stop_r = in && !cmp_less(P, sk[last - 1 - off]);
+            const unsigned long long ml = __ballot(stop_l), mr = __ballot(stop_r);
+            if (stop_l) stops_l[nl + __popcll(ml & lt)] = (unsigned short)(first + off);
+            if (stop_r) stops_r[nr + __popcll(mr & lt)] = (unsigned short)(last - 1 - off);
+            nl += __popcll(ml);
+            nr += __popcll(mr);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int n_pairs = min(nl, nr);
+        int K = 0;  // pairs with L_k < R_k: a prefix of the pairs
+        for (int k0 = 0; k0 < n_pairs; k0 += 64) {
+            const int k = k0 + lane;
+            const int c = __popcll(__ballot(k < n_pairs && stops_l[k] < stops_r[k]));
+            K += c;
+            if (c < 64) break;
+        }
+        for (int k = lane; k < K; k += 64) {  // every position takes part in at most one swap
+            const int L = stops_l[k], R = stops_r[k];
+            const float ka = sk[L], kb = sk[R];
+            const int va = sv[L], vb = sv[R];
+            sk[L] = kb; sv[L] = vb; sk[R] = ka; sv[R] = va;
+        }
+        const int Rk = K > 0 ? (int)stops_r[K - 1] : last;
+        const int cut = K < nl ? min((int)stops_l[K], Rk) : Rk;
+        // introsort(cut, last, depth-1); last = cut (same depth budget)
+        const Seg parts[2] = {{cut, last, seg.depth - 1}, {first, cut, seg.depth - 1}};
+        for (int q = 0; q < 2; q++) {
+            const int len = parts[q].last - parts[q].first;
+            if (len > SORT_THRESHOLD) {
+                if (lane == 0) stack[sp] = parts[q];
+                sp++;
+            } else if (len > 1) {
+                if (lane == 0) done[n_done] = (unsigned)parts[q].first | ((unsigned)len << 16);
+                n_done++;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // final_insertion_sort, restricted to each finished piece (elements never cross partition cuts): one lane each
+    for (int f = lane; f < n_done; f += 64) {
+        const int first = (int)(done[f] & 0xffffu), last = first + (int)(done[f] >> 16);
+        for (int i = first + 1; i < last; i++) {
+            const float kv = sk[i];
+            const int vv = sv[i];
+            int j = i;
+            while (j > first && cmp_less(kv, sk[j - 1])) { sk[j] = sk[j - 1]; sv[j] = sv[j - 1]; j--; }
+            sk[j] = kv; sv[j] = vv;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < n_whole; i += 64) { keys[base + i] = sk[i]; vals[base + i] = sv[i]; }
+}
+
+// The same partition for a long segment, by a 1024-thread workgroup.  The two-pointer loop of
+// SortArray::partitioner swaps the k-th element from the left that is not before the pivot with the k-th from
+// the right that is not after it, for as long as the former lies left of the latter; which elements those are
+// depends on the segment's contents before the call only.  So: list the "left stops" in ascending and the
+// "right stops" in descending position (block-wide prefix sums, 1024 elements per step), count the K pairs with
+// L_k < R_k (the stops move towards each other, so these are the first K), swap them all at once, and cut where
+// the loop would have stopped: min(L_K+1, R_K).
+__global__ __launch_bounds__(1024) void k_sort_level_big(const Seg* segs, const int* n_segs, float* keys, int* vals, int* stops_l, int* stops_r,
+                                                         Seg* next, int* next_count, Seg* next_big, int* big_count, Seg* finals, int* final_count) {
+    __shared__ int s_wave[16];
+    __shared__ int s_total;
+    __shared__ float s_keys[SORT_RANK_MAX];
+    const int sidx = blockIdx.x;
+    if (sidx >= *n_segs) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Seg seg = segs[sidx];
     const int first = seg.first, last = seg.last;
     if (seg.depth == 0) {
-        if (lane == 0) heap_sort(keys, vals, first, last);
-        return;  // already fully sorted; the final insertion pass leaves it unchanged
+        // the heapsort fallback, by counting when no two keys are equal (see k_sort_small)
+        const int n = last - first;
+        bool plain = n <= SORT_RANK_MAX;
+        float rk[SORT_RANK_MAX / 1024];
+        int rv[SORT_RANK_MAX / 1024], rank[SORT_RANK_MAX / 1024];
+        if (plain) {
+            for (int i = tid; i < n; i += 1024) s_keys[i] = keys[first + i];
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < SORT_RANK_MAX / 1024; t++) {
+                const int i = tid + 1024 * t;
+                rank[t] = -1;
+                if (i < n) {
+                    rk[t] = s_keys[i]; rv[t] = vals[first + i];
+                    int before = 0, same = 0;
+                    for (int j = 0; j < n; j++) { const float kj = s_keys[j]; before += cmp_less(kj, rk[t]) ? 1 : 0; same += kj == rk[t] ? 1 : 0; }
+                    rank[t] = before;
+                    plain = plain && same == 1;
+                }
+            }
+        }
+        if (tid == 0) s_total = 0;
+        __syncthreads();
+        if (!plain) s_total = 1;
+        __syncthreads();
+        if (s_total == 0) {
+#pragma unroll
+            for (int t = 0; t < SORT_RANK_MAX / 1024; t++) if (rank[t] >= 0) { keys[first + rank[t]] = rk[t]; vals[first + rank[t]] = rv[t]; }
+        } else if (tid == 0) {
+            heap_sort(keys, vals, first, last);
+        }
+        return;
     }
     const float P = median_of_3(keys[first], keys[first + (last - first) / 2], keys[last - 1]);
-
-    unsigned long long ML = 0, MR = 0;  // pending stops of the loaded chunks
-    int bl = first, br = last - 1;      // chunk bases: left chunk covers bl+lane, right chunk br-lane
-    int lf = first, rt = last;          // next unscanned positions (left inclusive, right exclusive)
-    float kL = 0.0f, kR = 0.0f;
-    int vL = 0, vR = 0;
-    int Rk = last;                      // position of the last swapped right element (R_0 = last)
-    int cut;
-    for (;;) {
-        while (ML == 0 && lf < last) {  // next 64 from the left: stops are elements with !(a < pivot)
-            bl = lf;
-            int i = bl + lane;
-            bool in = i < last;
-            if (in) { kL = keys[i]; vL = vals[i]; }
-            ML = __ballot(in && !cmp_less(kL, P));
-            lf += 64;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int n_stops[2];
+    for (int side = 0; side < 2; side++) {  // 0: left stops, ascending; 1: right stops, descending
+        int* out = side == 0 ? stops_l : stops_r;
+        int base = 0;
+        for (int chunk = 0; chunk < last - first; chunk += 1024) {
+            const int off = chunk + tid;
+            const bool in = off < last - first;
+            const int i = side == 0 ? first + off : last - 1 - off;
+            bool stop = false;
+            if (in) { const float k = keys[i]; stop = side == 0 ? !cmp_less(k, P) : !cmp_less(P, k); }
+            const unsigned long long m = __ballot(stop);
+            if (lane == 0) s_wave[wave] = __popcll(m);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < 16; w++) { const int c = s_wave[w]; total += c; before += w < wave ? c : 0; }
+            if (stop) out[first + base + before + __popcll(m & lt)] = i;
+            base += total;
+            __syncthreads();
         }
-        while (MR == 0 && rt > first) {  // next 64 from the right: stops are elements with !(pivot < a)
-            br = rt - 1;
-            int j = br - lane;
-            bool in = j >= first;
-            if (in) { kR = keys[j]; vR = vals[j]; }
-            MR = __ballot(in && !cmp_less(P, kR));
-            rt -= 64;
-        }
-        if (ML == 0) { cut = Rk; break; }
-        const int bitL = __builtin_ctzll(ML);
-        const int L = bl + bitL;
-        if (MR == 0) { cut = min(L, Rk); break; }
-        const int bitR = __builtin_ctzll(MR);
-        const int R = br - bitR;
-        if (L < R) {
-            float ka = __shfl(kL, bitL), kb = __shfl(kR, bitR);
-            int va = __shfl(vL, bitL), vb = __shfl(vR, bitR);
-            if (lane == 0) { keys[L] = kb; vals[L] = vb; keys[R] = ka; vals[R] = va; }
-            ML &= ML - 1;
-            MR &= MR - 1;
-            Rk = R;
-        } else {
-            cut = min(L, Rk);
-            break;
-        }
+        n_stops[side] = base;
     }
-    if (lane == 0) {
-        // introsort(cut, last, depth-1); last = cut (same depth budget)
+    __threadfence_block();
+    __syncthreads();
+    const int n_pairs = min(n_stops[0], n_stops[1]);
+    // K = number of k with L_k < R_k (a prefix of the pairs)
+    int mine = 0;
+    for (int k = tid; k < n_pairs; k += 1024) mine += stops_l[first + k] < stops_r[first + k] ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+    if (lane == 0) s_wave[wave] = mine;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < 16; w++) t += s_wave[w]; s_total = t; }
+    __syncthreads();
+    const int K = s_total;
+    for (int k = tid; k < K; k += 1024) {  // every position takes part in at most one swap
+        const int L = stops_l[first + k], R = stops_r[first + k];
+        const float ka = keys[L], kb = keys[R];
+        const int va = vals[L], vb = vals[R];
+        keys[L] = kb; vals[L] = vb; keys[R] = ka; vals[R] = va;
+    }
+    if (tid == 0) {
+        const int Rk = K > 0 ? stops_r[first + K - 1] : last;
+        const int cut = K < n_stops[0] ? min(stops_l[first + K], Rk) : Rk;
         Seg a = {cut, last, seg.depth - 1}, b = {first, cut, seg.depth - 1};
-        Seg parts[2] = {a, b};
-        for (int q = 0; q < 2; q++) {
-            int len = parts[q].last - parts[q].first;
-            if (len > SORT_THRESHOLD) next[atomicAdd(next_count, 1)] = parts[q];
-            else if (len > 1) finals[atomicAdd(final_count, 1)] = parts[q];
-        }
+        sort_emit(a, next, next_count, next_big, big_count, finals, final_count);
+        sort_emit(b, next, next_count, next_big, big_count, finals, final_count);
     }
 }
 
+// the queues' first entries: every call's range with SortArray::sort's depth budget, 2 * bitlog(length)
+__global__ void k_sort_seed(const Call* calls, int n_calls, Seg* small, int* small_count, Seg* big, int* big_count, Seg* finals, int* final_count) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_calls) return;
+    const int len = calls[c].end - calls[c].begin;
+    if (len < 2) return;
+    Seg r = {calls[c].begin, calls[c].end, 2 * (31 - __clz(len))};
+    sort_emit(r, small, small_count, big, big_count, finals, final_count);
+}
+
 // final_insertion_sort restricted to one finished segment (elements never cross partition cuts): stable
-__global__ void k_sort_final(const Seg* finals, int n, float* keys, int* vals) {
+__global__ void k_sort_final(const Seg* finals, const int* n_finals, float* keys, int* vals) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
+    if (s >= *n_finals) return;
     Seg seg = finals[s];
     for (int i = seg.first + 1; i < seg.last; i++) {
         float kv = keys[i];
@@ -663,10 +904,14 @@ struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    bool alloc(size_t count) {
-        if (p) { (void)hipFree(p); p = nullptr; }
+    size_t cap = 0;
+    bool alloc(size_t count) {  // contents are not kept; an allocation that is large enough is reused
         n = count;
-        return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)) == hipSuccess;
+        if (p && cap >= std::max<size_t>(count, 1)) return true;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        cap = std::max<size_t>(count, 1);
+        if (hipMalloc((void**)&p, cap * sizeof(T)) != hipSuccess) { p = nullptr; cap = 0; return false; }
+        return true;
     }
 };
 
@@ -720,43 +965,52 @@ struct BvhImpl : PtkBvh {
         if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return false; } \
     } while (0)
 
-// exact sort of every given range of (keys, vals): level-synchronous introsort emulation
-bool device_sort(hipStream_t st, const std::vector<Seg>& ranges, float* keys, int* vals, int n_total, std::string& err) {
-    std::vector<Seg> cur;
-    std::vector<Seg> finals_host;
-    for (const Seg& r : ranges) {
-        int len = r.last - r.first;
-        if (len > SORT_THRESHOLD) cur.push_back(r);
-        else if (len > 1) finals_host.push_back(r);
+// queues of device_sort, kept over the calls of one build
+struct SortWorkspace {
+    DevBuf<Seg> small, big_a, big_b, finals;
+    DevBuf<int> counters;  // [0] small segments, [1] segments for the final pass, [2 + l] long segments of level l
+    DevBuf<int> stops_l, stops_r;
+    int h_counts[2 + SORT_MAX_LEVELS + 4];
+};
+
+// Exact sort of the range of every call in (keys, vals), an emulation of SortArray::sort.  Segments longer than
+// SORT_BIG are partitioned level by level, four levels per host round trip; everything shorter is finished by one
+// launch of k_sort_small, and k_sort_final takes what never passed through it.  longest: the longest call;
+// covered: the sum of the calls' lengths.
+bool device_sort(hipStream_t st, SortWorkspace& ws, const Call* d_calls, int n_calls, int longest, size_t covered, float* keys, int* vals,
+                 int n_total, std::string& err) {
+    // segments of one queue are disjoint and longer than 1 (finals), SORT_THRESHOLD (small), SORT_BIG (big)
+    const size_t cap_finals = covered / 2 + 16, cap_small = covered / (SORT_THRESHOLD + 1) + 16, cap_big = covered / (SORT_BIG + 1) + 16;
+    const bool any_big = longest > SORT_BIG;
+    if (!ws.small.alloc(cap_small) || !ws.big_a.alloc(cap_big) || !ws.big_b.alloc(cap_big) || !ws.finals.alloc(cap_finals) ||
+        !ws.counters.alloc(2 + SORT_MAX_LEVELS + 4)) { err = "sort queues: out of memory"; return false; }
+    if (any_big && (!ws.stops_l.alloc(n_total) || !ws.stops_r.alloc(n_total))) { err = "sort queues: out of memory"; return false; }
+    CK(hipMemsetAsync(ws.counters.p, 0, sizeof ws.h_counts, st));
+    hipLaunchKernelGGL(k_sort_seed, dim3((n_calls + 255) / 256), dim3(256), 0, st, d_calls, n_calls, ws.small.p, ws.counters.p, ws.big_a.p,
+                       ws.counters.p + 2, ws.finals.p, ws.counters.p + 1);
+    CK(hipGetLastError());
+    if (any_big) {
+        int level = 0;
+        for (bool more = true; more;) {
+            if (level + 4 > SORT_MAX_LEVELS) { err = "sort did not terminate"; return false; }
+            for (int g = 0; g < 4; g++, level++) {
+                Seg* in = (level & 1) ? ws.big_b.p : ws.big_a.p;
+                Seg* out = (level & 1) ? ws.big_a.p : ws.big_b.p;
+                // more blocks than segments (the count is on the device): the others leave at once
+                hipLaunchKernelGGL(k_sort_level_big, dim3((unsigned)cap_big), dim3(1024), 0, st, in,
+                                   ws.counters.p + 2 + level, keys, vals, ws.stops_l.p, ws.stops_r.p, ws.small.p, ws.counters.p, out,
+                                   ws.counters.p + 2 + level + 1, ws.finals.p, ws.counters.p + 1);
+                CK(hipGetLastError());
+            }
+            CK(hipMemcpyAsync(ws.h_counts, ws.counters.p, sizeof(int) * (2 + level + 1), hipMemcpyDeviceToHost, st));
+            CK(hipStreamSynchronize(st));
+            more = ws.h_counts[2 + level] > 0;
+        }
     }
-    size_t cap = (size_t)n_total / 2 + ranges.size() + 16;
-    DevBuf<Seg> qa, qb, finals;
-    DevBuf<int> counters;
-    if (!qa.alloc(cap) || !qb.alloc(cap) || !finals.alloc(cap) || !counters.alloc(2)) { err = "sort queues: out of memory"; return false; }
-    int n_final = (int)finals_host.size();
-    if (n_final) CK(hipMemcpyAsync(finals.p, finals_host.data(), sizeof(Seg) * n_final, hipMemcpyHostToDevice, st));
-    int n_cur = (int)cur.size();
-    if (n_cur) CK(hipMemcpyAsync(qa.p, cur.data(), sizeof(Seg) * n_cur, hipMemcpyHostToDevice, st));
-    Seg* in = qa.p;
-    Seg* out = qb.p;
-    int guard = 0;
-    while (n_cur > 0) {
-        int h[2] = {0, n_final};
-        CK(hipMemcpyAsync(counters.p, h, sizeof h, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_sort_level, dim3(n_cur), dim3(64), 0, st, in, n_cur, keys, vals, out, counters.p, finals.p, counters.p + 1);
-        CK(hipGetLastError());
-        CK(hipMemcpyAsync(h, counters.p, sizeof h, hipMemcpyDeviceToHost, st));
-        CK(hipStreamSynchronize(st));
-        n_cur = h[0];
-        n_final = h[1];
-        std::swap(in, out);
-        if (++guard > 200) { err = "sort did not terminate"; return false; }
-    }
-    if (n_final > 0) {
-        hipLaunchKernelGGL(k_sort_final, dim3((n_final + 63) / 64), dim3(64), 0, st, finals.p, n_final, keys, vals);
-        CK(hipGetLastError());
-    }
-    CK(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_sort_small, dim3((unsigned)cap_small), dim3(64), 0, st, ws.small.p, ws.counters.p, keys, vals);
+    CK(hipGetLastError());
+    hipLaunchKernelGGL(k_sort_final, dim3((unsigned)((cap_finals + 63) / 64)), dim3(64), 0, st, ws.finals.p, ws.counters.p + 1, keys, vals);
+    CK(hipGetLastError());
     return true;
 }
 
@@ -868,8 +1122,8 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
         std::vector<PendingCall> calls = {{0, n_in, 0}};
         DevBuf<Call> d_calls;
         DevBuf<CallOut> d_out;
-        DevBuf<int> d_segcount;
-        DevBuf<unsigned char> d_move;
+        DevBuf<int> d_slices;  // per-slice bin counts of k_bins
+        SortWorkspace ws;
 
         // fixed-axis trees sort the whole list once before the recursion (pt_bvh_axis_sort.gd:193-194)
         if (T.type != 4) {
@@ -880,59 +1134,54 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
             if (!d_calls.alloc(1) || !d_out.alloc(1)) { err = "out of device memory"; return false; }
             CK(hipMemcpyAsync(d_calls.p, &c0, sizeof c0, hipMemcpyHostToDevice, st));
             CK(hipMemcpyAsync(d_out.p, &o0, sizeof o0, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_keys, dim3(1), dim3(64), 0, st, d_calls.p, 1, T.perm.p, T.in_aabb.p, d_out.p, keys.p);
+            hipLaunchKernelGGL(k_keys, dim3(1, (n_in + 1023) / 1024), dim3(256), 0, st, d_calls.p, 1, T.perm.p, T.in_aabb.p, d_out.p, keys.p);
             CK(hipGetLastError());
-            std::vector<Seg> r = {{0, n_in, n_in > 1 ? bitlog(n_in) * 2 : 0}};
-            if (!device_sort(st, r, keys.p, T.perm.p, n_in, err)) return false;
+            if (!device_sort(st, ws, d_calls.p, 1, n_in, (size_t)n_in, keys.p, T.perm.p, n_in, err)) return false;
         }
 
         for (int depth = 0; !calls.empty(); depth++) {
             if (depth >= MAX_DEPTH_LIMIT + 5) { err = "too much depth (reference assert)"; return false; }
             const int nc = (int)calls.size();
             std::vector<Call> hc(nc);
-            for (int i = 0; i < nc; i++) hc[i] = {calls[i].begin, calls[i].end};
-            if (!d_calls.alloc(nc) || !d_out.alloc(nc) || !d_segcount.alloc(nc) || !d_move.alloc(nc)) { err = "out of device memory"; return false; }
+            int longest = 0;
+            size_t covered = 0;
+            for (int i = 0; i < nc; i++) {
+                hc[i] = {calls[i].begin, calls[i].end};
+                longest = std::max(longest, calls[i].end - calls[i].begin);
+                covered += (size_t)(calls[i].end - calls[i].begin);
+            }
+            const int ny = std::min(64, (longest + 1023) / 1024);  // blocks along a call's range in k_keys, k_bins, k_partition
+            if (!d_calls.alloc(nc) || !d_out.alloc(nc)) { err = "out of device memory"; return false; }
             CK(hipMemcpyAsync(d_calls.p, hc.data(), sizeof(Call) * nc, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_list_box, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, T.in_kind.p, T.type, fixed_axis, d_out.p);
             CK(hipGetLastError());
             std::vector<CallOut> ho(nc);
             if (T.type == 4) {
-                hipLaunchKernelGGL(k_keys, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, d_out.p, keys.p);
+                hipLaunchKernelGGL(k_keys, dim3(nc, ny), dim3(256), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, d_out.p, keys.p);
                 CK(hipGetLastError());
-                std::vector<Seg> r(nc);
-                for (int i = 0; i < nc; i++) {
-                    int len = hc[i].end - hc[i].begin;
-                    r[i] = {hc[i].begin, hc[i].end, len > 1 ? bitlog(len) * 2 : 0};
-                }
-                if (!device_sort(st, r, keys.p, T.perm.p, n_in, err)) return false;
+                if (!device_sort(st, ws, d_calls.p, nc, longest, covered, keys.p, T.perm.p, n_in, err)) return false;
             }
-            CK(hipMemcpyAsync(ho.data(), d_out.p, sizeof(CallOut) * nc, hipMemcpyDeviceToHost, st));
-            CK(hipStreamSynchronize(st));
-            // segment_count (pt_bvh_axis_sort.gd:276,288-296)
-            std::vector<int> segc(nc, T.order);
-            for (int i = 0; i < nc; i++) {
-                if (depth >= MAX_DEPTH_LIMIT) {
-                    int mc = ho[i].mesh_count;
-                    if (mc >= T.order) { /* warning only */ }
-                    else if (mc > 0) segc[i] = T.order - mc;
-                }
-            }
-            CK(hipMemcpyAsync(d_segcount.p, segc.data(), sizeof(int) * nc, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_bins, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, d_segcount.p, d_out.p, bins.p);
+            // bins and the stable partition follow on the device; the host only needs the outcome
+            const bool at_limit = depth >= MAX_DEPTH_LIMIT;
+            if (!d_slices.alloc((size_t)nc * ny * 4 * MAXB)) { err = "out of device memory"; return false; }
+            hipLaunchKernelGGL(k_bins, dim3(nc, ny), dim3(256), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, T.order, at_limit ? 1 : 0, d_out.p, bins.p, d_slices.p);
+            CK(hipGetLastError());
+            hipLaunchKernelGGL(k_partition, dim3(nc, ny), dim3(256), 0, st, d_calls.p, nc, T.perm.p, tmp.p, d_out.p, bins.p, d_slices.p);
+            CK(hipGetLastError());
+            hipLaunchKernelGGL(k_partition_copy, dim3(nc, ny), dim3(256), 0, st, d_calls.p, nc, T.perm.p, tmp.p, d_out.p);
             CK(hipGetLastError());
             CK(hipMemcpyAsync(ho.data(), d_out.p, sizeof(CallOut) * nc, hipMemcpyDeviceToHost, st));
             CK(hipStreamSynchronize(st));
-            // which calls move elements: those with more than one non-empty bin (:314-325)
-            std::vector<unsigned char> mv(nc, 0);
+            std::vector<int> segc(nc, T.order);
+            std::vector<unsigned char> mv(nc, 0);  // calls that moved elements: those with more than one non-empty bin (:314-325)
             for (int i = 0; i < nc; i++) {
                 if (ho[i].error) { err = "a node's centre falls outside its list's bins (reference assert 0 <= index < segment_count)"; return false; }
+                const int mc = ho[i].mesh_count;
+                if (at_limit && mc > 0 && mc < T.order) segc[i] = T.order - mc;  // segment_count (:276,288-296)
                 int nonempty = 0;
                 for (int b = 0; b < segc[i]; b++) nonempty += ho[i].counts[b] > 0;
                 mv[i] = nonempty > 1;
             }
-            CK(hipMemcpyAsync(d_move.p, mv.data(), nc, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_partition, dim3(nc), dim3(64), 0, st, d_calls.p, nc, d_move.p, T.perm.p, tmp.p, d_out.p, bins.p);
-            CK(hipGetLastError());
 
             // host: one new node per non-empty bin, in bin order (:327-371)
             std::vector<PendingCall> next;
@@ -1042,23 +1291,6 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
     if (!T.node_aabb.alloc((size_t)nn * 6)) { err = "out of device memory"; return false; }
     CK(hipMemsetAsync(T.node_aabb.p, 0, sizeof(float) * 6 * nn, st));
     {
-        std::vector<int> ln, ob, oc;
-        for (int i = 0; i < nn; i++) if (T.nodes[i].kind == N_LEAF) { ln.push_back(i); ob.push_back(T.nodes[i].obj_begin); oc.push_back(T.nodes[i].obj_count); }
-        int nl = (int)ln.size();
-        if (nl) {
-            DevBuf<int> dln, dob, doc;
-            if (!dln.alloc(nl) || !dob.alloc(nl) || !doc.alloc(nl)) { err = "out of device memory"; return false; }
-            CK(hipMemcpyAsync(dln.p, ln.data(), sizeof(int) * nl, hipMemcpyHostToDevice, st));
-            CK(hipMemcpyAsync(dob.p, ob.data(), sizeof(int) * nl, hipMemcpyHostToDevice, st));
-            CK(hipMemcpyAsync(doc.p, oc.data(), sizeof(int) * nl, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_leaf_boxes, dim3((nl + 127) / 128), dim3(128), 0, st, nl, dln.p, dob.p, doc.p, T.perm.p, T.in_aabb.p, T.node_aabb.p);
-            CK(hipGetLastError());
-            CK(hipStreamSynchronize(st));
-        }
-        for (int i = 0; i < nn; i++) if (T.nodes[i].kind == N_SOCKET) {
-            hipLaunchKernelGGL(k_copy_box, dim3(1), dim3(1), 0, st, T.in_aabb.p, N + T.nodes[i].mesh_slot, T.node_aabb.p, i);
-            CK(hipGetLastError());
-        }
         // depth of every node, then inner nodes deepest first
         std::vector<int> depth(nn, 0), order_bfs = {0};
         int maxd = 0;
@@ -1066,25 +1298,51 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
             int x = order_bfs[q];
             for (int c : T.nodes[x].children) { depth[c] = depth[x] + 1; maxd = std::max(maxd, depth[c]); order_bfs.push_back(c); }
         }
+        // one upload: [leaf node | first object | object count] per leaf, then [node | first child slot | child count]
+        // per inner node grouped by depth (deepest first), then the child lists
+        std::vector<int> ln, ob, oc;
+        for (int i = 0; i < nn; i++) if (T.nodes[i].kind == N_LEAF) { ln.push_back(i); ob.push_back(T.nodes[i].obj_begin); oc.push_back(T.nodes[i].obj_count); }
+        const int nl = (int)ln.size();
+        std::vector<std::vector<int>> by_depth(maxd + 1);
+        for (int i = 0; i < nn; i++) if (T.nodes[i].kind == N_INNER && (i == 0 || depth[i] > 0)) by_depth[depth[i]].push_back(i);
+        std::vector<int> nd, cb, cc, ch, group_first, group_count;
         for (int d = maxd; d >= 0; d--) {
-            std::vector<int> nd, cb, cc, ch;
-            for (int i = 0; i < nn; i++) if (depth[i] == d && T.nodes[i].kind == N_INNER && (i == 0 || order_bfs.size() > 0)) {
-                if (i != 0 && depth[i] == 0) continue;
+            if (by_depth[d].empty()) continue;
+            group_first.push_back((int)nd.size());
+            group_count.push_back((int)by_depth[d].size());
+            for (int i : by_depth[d]) {
                 nd.push_back(i); cb.push_back((int)ch.size()); cc.push_back((int)T.nodes[i].children.size());
                 for (int c : T.nodes[i].children) ch.push_back(c);
             }
-            int k = (int)nd.size();
-            if (!k) continue;
-            DevBuf<int> dnd, dcb, dcc, dch;
-            if (!dnd.alloc(k) || !dcb.alloc(k) || !dcc.alloc(k) || !dch.alloc(ch.size())) { err = "out of device memory"; return false; }
-            CK(hipMemcpyAsync(dnd.p, nd.data(), sizeof(int) * k, hipMemcpyHostToDevice, st));
-            CK(hipMemcpyAsync(dcb.p, cb.data(), sizeof(int) * k, hipMemcpyHostToDevice, st));
-            CK(hipMemcpyAsync(dcc.p, cc.data(), sizeof(int) * k, hipMemcpyHostToDevice, st));
-            if (!ch.empty()) CK(hipMemcpyAsync(dch.p, ch.data(), sizeof(int) * ch.size(), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_inner_boxes, dim3((k + 127) / 128), dim3(128), 0, st, k, dnd.p, dcb.p, dcc.p, dch.p, T.node_aabb.p);
-            CK(hipGetLastError());
-            CK(hipStreamSynchronize(st));
         }
+        const int ni = (int)nd.size();
+        std::vector<int> packed;
+        packed.reserve((size_t)3 * nl + 3 * ni + ch.size());
+        packed.insert(packed.end(), ln.begin(), ln.end());
+        packed.insert(packed.end(), ob.begin(), ob.end());
+        packed.insert(packed.end(), oc.begin(), oc.end());
+        packed.insert(packed.end(), nd.begin(), nd.end());
+        packed.insert(packed.end(), cb.begin(), cb.end());
+        packed.insert(packed.end(), cc.begin(), cc.end());
+        packed.insert(packed.end(), ch.begin(), ch.end());
+        DevBuf<int> d_packed;
+        if (!d_packed.alloc(packed.size())) { err = "out of device memory"; return false; }
+        if (!packed.empty()) CK(hipMemcpyAsync(d_packed.p, packed.data(), sizeof(int) * packed.size(), hipMemcpyHostToDevice, st));
+        const int *d_ln = d_packed.p, *d_ob = d_ln + nl, *d_oc = d_ob + nl, *d_nd = d_oc + nl, *d_cb = d_nd + ni, *d_cc = d_cb + ni, *d_ch = d_cc + ni;
+        if (nl) {
+            hipLaunchKernelGGL(k_leaf_boxes, dim3((nl + 127) / 128), dim3(128), 0, st, nl, d_ln, d_ob, d_oc, T.perm.p, T.in_aabb.p, T.node_aabb.p);
+            CK(hipGetLastError());
+        }
+        for (int i = 0; i < nn; i++) if (T.nodes[i].kind == N_SOCKET) {
+            hipLaunchKernelGGL(k_copy_box, dim3(1), dim3(1), 0, st, T.in_aabb.p, N + T.nodes[i].mesh_slot, T.node_aabb.p, i);
+            CK(hipGetLastError());
+        }
+        for (size_t g = 0; g < group_first.size(); g++) {
+            const int k = group_count[g], f = group_first[g];
+            hipLaunchKernelGGL(k_inner_boxes, dim3((k + 127) / 128), dim3(128), 0, st, k, d_nd + f, d_cb + f, d_cc + f, d_ch, T.node_aabb.p);
+            CK(hipGetLastError());
+        }
+        CK(hipStreamSynchronize(st));
     }
     return true;
 }

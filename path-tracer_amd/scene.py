@@ -31,6 +31,7 @@ from .godot_math import AABB, Transform3D, f32, normalized, cross, vec3, xform_a
 NOT_OBJECT, SPHERE, PLANE, TRIANGLE, OBJECT_TYPE_MAX = 0, 1, 2, 3, 4
 # PTBVHTree.BVHType, pt_bvh_tree.gd:40-46
 BVH_EMPTY, BVH_X_SORTED, BVH_Y_SORTED, BVH_Z_SORTED, BVH_XYZ_SORTED = 0, 1, 2, 3, 4
+BVH_SAH = 5  # binned surface-area-heuristic builder of libptk (no counterpart in the plugin)
 
 
 def make_object_id(index: int, type_: int) -> int:

@@ -86,6 +86,23 @@ def test_identical_objects_depth_limit(pta, rd):
     _check("identical", *_both(pta, rd, scene, 8, 4))
 
 
+@pytest.mark.parametrize("step", [0, 5])
+def test_sort_depth_budget_runs_out(pta, rd, step):
+    """The 4099-sphere random scene's X keys drive SortArray::introsort through its whole depth budget (median-of-3
+    keeps picking near-extreme pivots), so a 1679-element segment ends in the heapsort fallback (partial_sort).
+    step 0: all keys distinct (the device sorts such a segment by counting); step 5: every fifth sphere sits on
+    its neighbour's centre, so the segment holds equal keys and the heapsort's own order among them shows."""
+    sc, gm = pta.scene, pta.godot_math
+    src = pta.scenes.random_spheres_scene(grid=32, seed=5)
+    scene = sc.PTScene(default_bvh=sc.BVH_X_SORTED)
+    spheres = list(src.scene_spheres)
+    for i, s in enumerate(spheres):
+        twin = spheres[i - 1] if step and i % step == 1 else s
+        scene.add_object(sc.PTSphere(transform=gm.Transform3D(origin=tuple(float(v) for v in twin.position)), radius=float(twin.radius)))
+    for t in (1, 4):
+        _check(f"depth-budget/step{step}/type{t}", *_both(pta, rd, scene, 8, t))
+
+
 def test_atrium_64k(pta, rd):
     """65 536-triangle stand-in: deep recursion, large sorts, one mesh socket."""
     scene = pta.scenes.atrium_scene(65536, seed=7)
