@@ -137,11 +137,35 @@ struct CallOut {
     int pad[3];
 };
 
+// ---- queues of the sort (an emulation of Godot's SortArray, further below) ---------------------------
+struct Seg {
+    int first, last;  // range of the list
+    int depth;        // introsort's remaining depth budget
+    int axis;         // the keys are the boxes' centres on this axis
+};
+constexpr int SORT_BIG = 512;          // segments longer than this are partitioned by a whole 1024-thread workgroup
+constexpr int SORT_RANK_MAX = 8192;    // longest segment whose heapsort fallback is done by counting
+constexpr int SORT_LEVEL_GROUP = 8;    // long-segment levels launched per host round trip
+constexpr int SORT_MAX_LEVELS = 72;    // more than the largest depth budget, 2 * bitlog(2^31)
+constexpr int SORT_COUNTERS = 2 + SORT_MAX_LEVELS + SORT_LEVEL_GROUP;  // [0] short segments, [2 + l] long segments of level l
+
+// a segment that still needs work goes to the queue of the long or of the short segments
+DEV void sort_emit(Seg part, Seg* small, int* small_count, Seg* big, int* big_count) {
+    const int len = part.last - part.first;
+    if (len > SORT_BIG) big[atomicAdd(big_count, 1)] = part;
+    else if (len > 1) small[atomicAdd(small_count, 1)] = part;
+}
+// SortArray::sort's depth budget: 2 * bitlog(length)
+DEV int sort_depth_budget(int len) { return 2 * (31 - __clz(len)); }
+
 // ---- per-call kernels (one wave per call) ------------------------------------------------------
 // list box: sequential merge chain in list order (get_array_aabb, pt_bvh_axis_sort.gd:512-516), then
 // .abs().grow(1e-6) (:277); also counts mesh sockets and picks the axis (:279-280).
+// With sort_small given (longest-axis trees, which sort every list): also queues the call's range for the sort
+// (counters sort_now) and clears the counters the next level will use (sort_next).
 __global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls, const int* perm, const float* in_aabb,
-                                                 const int* in_kind, int type, int fixed_axis, CallOut* out) {
+                                                 const int* in_kind, int type, int fixed_axis, CallOut* out, Seg* sort_small,
+                                                 Seg* sort_big, int* sort_now, int* sort_next) {
     __shared__ __align__(16) float tr[6][64];
     int c = blockIdx.x;
     if (c >= n_calls) return;
@@ -265,7 +289,13 @@ __global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls,
         o.error = 0;
         o.pad[0] = o.pad[1] = o.pad[2] = 0;
         out[c] = o;
+        if (sort_small && call.end - call.begin > 1) {
+            Seg r = {call.begin, call.end, sort_depth_budget(call.end - call.begin), o.axis};
+            sort_emit(r, sort_small, sort_now, sort_big, sort_now + 2);
+        }
     }
+    if (sort_small && c == 0)
+        for (int i = lane; i < SORT_COUNTERS; i += 64) sort_next[i] = 0;
 }
 
 // sort key of every element of a call: centre of its box on the call's axis (pt_bvh_axis_sort.gd:180-181)
@@ -375,6 +405,71 @@ __global__ __launch_bounds__(256) void k_partition(const Call* calls, int n_call
         }
     }
 }
+// k_bins and k_partition in one for levels whose calls all have at most 1024 elements: the block keeps its
+// elements in registers, so the list is rewritten in place.
+__global__ __launch_bounds__(256) void k_bin_partition(const Call* calls, int n_calls, int* perm, const float* in_aabb, int order,
+                                                       int at_depth_limit, CallOut* co) {
+    __shared__ int s_cnt[4][MAXB];
+    __shared__ int s_err;
+    int c = blockIdx.x;
+    if (c >= n_calls) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Call call = calls[c];
+    const int slice_len = call_slice_len(call.end - call.begin, 1);  // at most 256
+    const int begin = call.begin + wave * slice_len, end = min(call.end, begin + slice_len);
+    const int axis = co[c].axis;
+    const float lo = co[c].aabb[axis], size = co[c].aabb[3 + axis];
+    const int segs = call_segment_count(order, at_depth_limit != 0, co[c].mesh_count);
+    double segment = (double)(size / (float)segs);
+    int v[4], bin[4], counts[MAXB];
+    for (int b = 0; b < MAXB; b++) counts[b] = 0;
+    int err = 0;
+    if (tid == 0) s_err = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int i = begin + 64 * t + lane;
+        const bool in = i < end;
+        bin[t] = -1;
+        v[t] = 0;
+        if (in) {
+            v[t] = perm[i];
+            A6 a = a6_load(in_aabb, v[t]);
+            float rel = a6_center(a, axis) - lo;
+            double q = floor((double)rel / segment);
+            if (!(q >= 0.0 && q < (double)segs)) { err = 1; q = 0.0; }
+            bin[t] = (int)q;
+        }
+        for (int b = 0; b < MAXB; b++) counts[b] += __popcll(__ballot(in && bin[t] == b));
+    }
+    if (lane == 0) for (int b = 0; b < MAXB; b++) s_cnt[wave][b] = counts[b];
+    __syncthreads();  // every element of the call is in a register by now
+    if (__any(err) && lane == 0) s_err = 1;
+    int offs[MAXB];
+    int run = call.begin, occupied = 0;
+    for (int b = 0; b < MAXB; b++) {
+        int total = 0, before = 0;
+        for (int w = 0; w < 4; w++) { total += s_cnt[w][b]; before += w < wave ? s_cnt[w][b] : 0; }
+        offs[b] = run + before;
+        run += total;
+        occupied += total > 0;
+        counts[b] = total;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int b = 0; b < MAXB; b++) co[c].counts[b] = counts[b];
+        co[c].error = s_err;
+    }
+    if (occupied <= 1) return;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        for (int b = 0; b < MAXB; b++) {
+            const unsigned long long m = __ballot(bin[t] == b);
+            if (bin[t] == b) perm[offs[b] + __popcll(m & lt)] = v[t];
+            offs[b] += __popcll(m);
+        }
+    }
+}
 __global__ __launch_bounds__(256) void k_partition_copy(const Call* calls, int n_calls, int* perm, const int* tmp, const CallOut* co) {
     int c = blockIdx.x;
     if (c >= n_calls) return;
@@ -386,9 +481,6 @@ __global__ __launch_bounds__(256) void k_partition_copy(const Call* calls, int n
 }
 
 // ---- exact emulation of Godot's SortArray on (key descending, payload) ------------------------------
-struct Seg {
-    int first, last, depth;
-};
 DEV bool cmp_less(float a, float b) { return a > b; }  // comparator of pt_bvh_axis_sort.gd:180-181
 
 DEV float median_of_3(float a, float b, float c) {
@@ -442,26 +534,15 @@ DEV void heap_sort(float* k, int* v, int first, int last) {
     }
 }
 
-constexpr int SORT_BIG = 1024;     // segments longer than this are partitioned by a whole 1024-thread workgroup
-constexpr int SORT_RANK_MAX = 8192;  // longest segment whose heapsort fallback is done by counting
-constexpr int SORT_MAX_LEVELS = 72;  // more than the largest depth budget, 2 * bitlog(2^31)
-
-// where the two parts of a partitioned segment go: the queue of the next level (by size) or the final insertion pass
-DEV void sort_emit(Seg part, Seg* next, int* next_count, Seg* next_big, int* big_count, Seg* finals, int* final_count) {
-    const int len = part.last - part.first;
-    if (len > SORT_BIG) next_big[atomicAdd(big_count, 1)] = part;
-    else if (len > SORT_THRESHOLD) next[atomicAdd(next_count, 1)] = part;
-    else if (len > 1) finals[atomicAdd(final_count, 1)] = part;
-}
-
-// Sorts one segment of at most SORT_BIG elements down to pieces of at most SORT_THRESHOLD: one wave copies it to
-// LDS and replays SortArray::introsort over it with an explicit stack (the two parts of a partition are independent,
-// so the order in which they are taken does not matter), then writes it back.  A partition lowers the depth budget by
-// one and a segment with no budget left is heap-sorted without children, so the stack never holds more than
-// budget + 1 entries.  The partition is the one of k_sort_level_big below, with the stop lists in LDS too.  The
-// pieces of at most SORT_THRESHOLD elements get their share of the final insertion pass before the copy back.
-__global__ __launch_bounds__(64) void k_sort_small(const Seg* segs, const int* n_segs, float* keys, int* vals) {
-    __shared__ Seg stack[72];
+// Sorts one segment of at most SORT_BIG elements completely: one wave brings its keys (the boxes' centres on the
+// segment's axis) and payloads to LDS and replays SortArray::introsort over it with an explicit stack (the two parts
+// of a partition are independent, so the order in which they are taken does not matter), then writes the payloads
+// back.  A partition lowers the depth budget by one and a segment with no budget left is heap-sorted without
+// children, so the stack never holds more than budget + 1 entries.  The partition is the one of k_sort_level_big
+// below, with the stop lists in LDS too.  The pieces of at most SORT_THRESHOLD elements get their share of the
+// final insertion pass before the copy back.
+__global__ __launch_bounds__(64) void k_sort_small(const Seg* segs, const int* n_segs, const float* in_aabb, int* vals) {
+    __shared__ Seg stack[SORT_MAX_LEVELS + 4];
     __shared__ float sk[SORT_BIG];
     __shared__ int sv[SORT_BIG];
     __shared__ unsigned short stops_l[SORT_BIG], stops_r[SORT_BIG];
@@ -473,8 +554,12 @@ __global__ __launch_bounds__(64) void k_sort_small(const Seg* segs, const int* n
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const Seg whole = segs[s];
     const int base = whole.first, n_whole = whole.last - whole.first;  // positions below are relative to base
-    for (int i = lane; i < n_whole; i += 64) { sk[i] = keys[base + i]; sv[i] = vals[base + i]; }
-    if (lane == 0) { Seg r = {0, n_whole, whole.depth}; stack[0] = r; }
+    for (int i = lane; i < n_whole; i += 64) {
+        const int v = vals[base + i];
+        sv[i] = v;
+        sk[i] = a6_center(a6_load(in_aabb, v), whole.axis);
+    }
+    if (lane == 0) { Seg r = {0, n_whole, whole.depth, whole.axis}; stack[0] = r; }
     int sp = 1;
     while (sp > 0) {
         __builtin_amdgcn_wave_barrier();  // one wave: its LDS accesses execute in program order
@@ -482,6 +567,13 @@ __global__ __launch_bounds__(64) void k_sort_small(const Seg* segs, const int* n
         __builtin_amdgcn_wave_barrier();
         const int first = seg.first, last = seg.last;
         const int n = last - first;
+        if (n <= SORT_THRESHOLD) {  // introsort leaves such a piece to the final insertion pass
+            if (n > 1) {
+                if (lane == 0) done[n_done] = (unsigned)first | ((unsigned)n << 16);
+                n_done++;
+            }
+            continue;
+        }
         if (seg.depth == 0) {
             // SortArray::partial_sort over the whole segment, a heapsort.  With no two keys equal (and none a NaN) its
             // result is simply the sorted order, found here by counting, for every element, the elements before it;
@@ -542,17 +634,12 @@ __global__ __launch_bounds__(64) void k_sort_small(const Seg* segs, const int* n
         const int Rk = K > 0 ? (int)stops_r[K - 1] : last;
         const int cut = K < nl ? min((int)stops_l[K], Rk) : Rk;
         // introsort(cut, last, depth-1); last = cut (same depth budget)
-        const Seg parts[2] = {{cut, last, seg.depth - 1}, {first, cut, seg.depth - 1}};
-        for (int q = 0; q < 2; q++) {
-            const int len = parts[q].last - parts[q].first;
-            if (len > SORT_THRESHOLD) {
-                if (lane == 0) stack[sp] = parts[q];
-                sp++;
-            } else if (len > 1) {
-                if (lane == 0) done[n_done] = (unsigned)parts[q].first | ((unsigned)len << 16);
-                n_done++;
-            }
+        if (lane == 0) {
+            Seg a = {cut, last, seg.depth - 1, seg.axis}, b = {first, cut, seg.depth - 1, seg.axis};
+            stack[sp] = a;
+            stack[sp + 1] = b;
         }
+        sp += 2;
     }
     __builtin_amdgcn_wave_barrier();
     // final_insertion_sort, restricted to each finished piece (elements never cross partition cuts): one lane each
@@ -567,7 +654,7 @@ __global__ __launch_bounds__(64) void k_sort_small(const Seg* segs, const int* n
         }
     }
     __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < n_whole; i += 64) { keys[base + i] = sk[i]; vals[base + i] = sv[i]; }
+    for (int i = lane; i < n_whole; i += 64) vals[base + i] = sv[i];
 }
 
 // The same partition for a long segment, by a 1024-thread workgroup.  The two-pointer loop of
@@ -578,7 +665,7 @@ __global__ __launch_bounds__(64) void k_sort_small(const Seg* segs, const int* n
 // L_k < R_k (the stops move towards each other, so these are the first K), swap them all at once, and cut where
 // the loop would have stopped: min(L_K+1, R_K).
 __global__ __launch_bounds__(1024) void k_sort_level_big(const Seg* segs, const int* n_segs, float* keys, int* vals, int* stops_l, int* stops_r,
-                                                         Seg* next, int* next_count, Seg* next_big, int* big_count, Seg* finals, int* final_count) {
+                                                         Seg* next, int* next_count, Seg* next_big, int* big_count) {
     __shared__ int s_wave[16];
     __shared__ int s_total;
     __shared__ float s_keys[SORT_RANK_MAX];
@@ -665,37 +752,17 @@ __global__ __launch_bounds__(1024) void k_sort_level_big(const Seg* segs, const 
     if (tid == 0) {
         const int Rk = K > 0 ? stops_r[first + K - 1] : last;
         const int cut = K < n_stops[0] ? min(stops_l[first + K], Rk) : Rk;
-        Seg a = {cut, last, seg.depth - 1}, b = {first, cut, seg.depth - 1};
-        sort_emit(a, next, next_count, next_big, big_count, finals, final_count);
-        sort_emit(b, next, next_count, next_big, big_count, finals, final_count);
+        Seg a = {cut, last, seg.depth - 1, seg.axis}, b = {first, cut, seg.depth - 1, seg.axis};
+        sort_emit(a, next, next_count, next_big, big_count);
+        sort_emit(b, next, next_count, next_big, big_count);
     }
 }
 
-// the queues' first entries: every call's range with SortArray::sort's depth budget, 2 * bitlog(length)
-__global__ void k_sort_seed(const Call* calls, int n_calls, Seg* small, int* small_count, Seg* big, int* big_count, Seg* finals, int* final_count) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_calls) return;
-    const int len = calls[c].end - calls[c].begin;
-    if (len < 2) return;
-    Seg r = {calls[c].begin, calls[c].end, 2 * (31 - __clz(len))};
-    sort_emit(r, small, small_count, big, big_count, finals, final_count);
-}
-
-// final_insertion_sort restricted to one finished segment (elements never cross partition cuts): stable
-__global__ void k_sort_final(const Seg* finals, const int* n_finals, float* keys, int* vals) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= *n_finals) return;
-    Seg seg = finals[s];
-    for (int i = seg.first + 1; i < seg.last; i++) {
-        float kv = keys[i];
-        int vv = vals[i];
-        int j = i;
-        while (j > seg.first && cmp_less(kv, keys[j - 1])) {
-            keys[j] = keys[j - 1]; vals[j] = vals[j - 1];
-            j--;
-        }
-        keys[j] = kv; vals[j] = vv;
-    }
+// the queue's first entry for a fixed-axis tree: the whole list
+__global__ void k_sort_seed(int n, int axis, Seg* small, int* small_count, Seg* big, int* big_count) {
+    if (blockIdx.x != 0 || threadIdx.x != 0 || n < 2) return;
+    Seg r = {0, n, sort_depth_budget(n), axis};
+    sort_emit(r, small, small_count, big, big_count);
 }
 
 // ---- tree finishing ---------------------------------------------------------------------------------
@@ -967,49 +1034,43 @@ struct BvhImpl : PtkBvh {
 
 // queues of device_sort, kept over the calls of one build
 struct SortWorkspace {
-    DevBuf<Seg> small, big_a, big_b, finals;
-    DevBuf<int> counters;  // [0] small segments, [1] segments for the final pass, [2 + l] long segments of level l
+    DevBuf<Seg> small, big_a, big_b;
+    DevBuf<int> counters;  // two sets of SORT_COUNTERS, used by alternate levels of the build
     DevBuf<int> stops_l, stops_r;
-    int h_counts[2 + SORT_MAX_LEVELS + 4];
+    int h_counts[SORT_COUNTERS];
+    bool reserve(size_t covered, int n_total, bool any_big) {
+        // segments of one queue are disjoint and longer than 1 (small) or SORT_BIG (big)
+        if (!small.alloc(covered / 2 + 16) || !big_a.alloc(covered / (SORT_BIG + 1) + 16) || !big_b.alloc(covered / (SORT_BIG + 1) + 16)) return false;
+        return !any_big || (stops_l.alloc(n_total) && stops_r.alloc(n_total));
+    }
 };
 
-// Exact sort of the range of every call in (keys, vals), an emulation of SortArray::sort.  Segments longer than
-// SORT_BIG are partitioned level by level, four levels per host round trip; everything shorter is finished by one
-// launch of k_sort_small, and k_sort_final takes what never passed through it.  longest: the longest call;
-// covered: the sum of the calls' lengths.
-bool device_sort(hipStream_t st, SortWorkspace& ws, const Call* d_calls, int n_calls, int longest, size_t covered, float* keys, int* vals,
-                 int n_total, std::string& err) {
-    // segments of one queue are disjoint and longer than 1 (finals), SORT_THRESHOLD (small), SORT_BIG (big)
-    const size_t cap_finals = covered / 2 + 16, cap_small = covered / (SORT_THRESHOLD + 1) + 16, cap_big = covered / (SORT_BIG + 1) + 16;
-    const bool any_big = longest > SORT_BIG;
-    if (!ws.small.alloc(cap_small) || !ws.big_a.alloc(cap_big) || !ws.big_b.alloc(cap_big) || !ws.finals.alloc(cap_finals) ||
-        !ws.counters.alloc(2 + SORT_MAX_LEVELS + 4)) { err = "sort queues: out of memory"; return false; }
-    if (any_big && (!ws.stops_l.alloc(n_total) || !ws.stops_r.alloc(n_total))) { err = "sort queues: out of memory"; return false; }
-    CK(hipMemsetAsync(ws.counters.p, 0, sizeof ws.h_counts, st));
-    hipLaunchKernelGGL(k_sort_seed, dim3((n_calls + 255) / 256), dim3(256), 0, st, d_calls, n_calls, ws.small.p, ws.counters.p, ws.big_a.p,
-                       ws.counters.p + 2, ws.finals.p, ws.counters.p + 1);
-    CK(hipGetLastError());
+// Exact sort of the queued ranges of vals by their boxes' centres, an emulation of SortArray::sort.  The queues of
+// counter set `set` hold the ranges (k_list_box or k_sort_seed put them there).  Segments longer than SORT_BIG
+// (keys: their centres, by k_keys) are partitioned level by level, SORT_LEVEL_GROUP levels per host round trip;
+// everything shorter is finished by one launch of k_sort_small.  covered: the sum of the ranges' lengths.
+bool device_sort(hipStream_t st, SortWorkspace& ws, int set, bool any_big, size_t covered, float* keys, const float* in_aabb, int* vals,
+                 std::string& err) {
+    int* counters = ws.counters.p + set * SORT_COUNTERS;
+    const size_t cap_small = covered / 2 + 16, cap_big = covered / (SORT_BIG + 1) + 16;
     if (any_big) {
         int level = 0;
         for (bool more = true; more;) {
-            if (level + 4 > SORT_MAX_LEVELS) { err = "sort did not terminate"; return false; }
-            for (int g = 0; g < 4; g++, level++) {
+            if (level + SORT_LEVEL_GROUP > SORT_MAX_LEVELS) { err = "sort did not terminate"; return false; }
+            for (int g = 0; g < SORT_LEVEL_GROUP; g++, level++) {
                 Seg* in = (level & 1) ? ws.big_b.p : ws.big_a.p;
                 Seg* out = (level & 1) ? ws.big_a.p : ws.big_b.p;
                 // more blocks than segments (the count is on the device): the others leave at once
-                hipLaunchKernelGGL(k_sort_level_big, dim3((unsigned)cap_big), dim3(1024), 0, st, in,
-                                   ws.counters.p + 2 + level, keys, vals, ws.stops_l.p, ws.stops_r.p, ws.small.p, ws.counters.p, out,
-                                   ws.counters.p + 2 + level + 1, ws.finals.p, ws.counters.p + 1);
+                hipLaunchKernelGGL(k_sort_level_big, dim3((unsigned)cap_big), dim3(1024), 0, st, in, counters + 2 + level, keys, vals, ws.stops_l.p,
+                                   ws.stops_r.p, ws.small.p, counters, out, counters + 2 + level + 1);
                 CK(hipGetLastError());
             }
-            CK(hipMemcpyAsync(ws.h_counts, ws.counters.p, sizeof(int) * (2 + level + 1), hipMemcpyDeviceToHost, st));
+            CK(hipMemcpyAsync(ws.h_counts, counters, sizeof(int) * (2 + level + 1), hipMemcpyDeviceToHost, st));
             CK(hipStreamSynchronize(st));
             more = ws.h_counts[2 + level] > 0;
         }
     }
-    hipLaunchKernelGGL(k_sort_small, dim3((unsigned)cap_small), dim3(64), 0, st, ws.small.p, ws.counters.p, keys, vals);
-    CK(hipGetLastError());
-    hipLaunchKernelGGL(k_sort_final, dim3((unsigned)((cap_finals + 63) / 64)), dim3(64), 0, st, ws.finals.p, ws.counters.p + 1, keys, vals);
+    hipLaunchKernelGGL(k_sort_small, dim3((unsigned)cap_small), dim3(64), 0, st, ws.small.p, counters, in_aabb, vals);
     CK(hipGetLastError());
     return true;
 }
@@ -1124,6 +1185,8 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
         DevBuf<CallOut> d_out;
         DevBuf<int> d_slices;  // per-slice bin counts of k_bins
         SortWorkspace ws;
+        if (!ws.counters.alloc(2 * SORT_COUNTERS)) { err = "out of device memory"; return false; }
+        CK(hipMemsetAsync(ws.counters.p, 0, sizeof(int) * 2 * SORT_COUNTERS, st));
 
         // fixed-axis trees sort the whole list once before the recursion (pt_bvh_axis_sort.gd:193-194)
         if (T.type != 4) {
@@ -1131,12 +1194,18 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
             CallOut o0;
             memset(&o0, 0, sizeof o0);
             o0.axis = fixed_axis;
-            if (!d_calls.alloc(1) || !d_out.alloc(1)) { err = "out of device memory"; return false; }
-            CK(hipMemcpyAsync(d_calls.p, &c0, sizeof c0, hipMemcpyHostToDevice, st));
-            CK(hipMemcpyAsync(d_out.p, &o0, sizeof o0, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_keys, dim3(1, (n_in + 1023) / 1024), dim3(256), 0, st, d_calls.p, 1, T.perm.p, T.in_aabb.p, d_out.p, keys.p);
+            const bool any_big = n_in > SORT_BIG;
+            if (!d_calls.alloc(1) || !d_out.alloc(1) || !ws.reserve((size_t)n_in, n_in, any_big)) { err = "out of device memory"; return false; }
+            if (any_big) {
+                CK(hipMemcpyAsync(d_calls.p, &c0, sizeof c0, hipMemcpyHostToDevice, st));
+                CK(hipMemcpyAsync(d_out.p, &o0, sizeof o0, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_keys, dim3(1, (n_in + 1023) / 1024), dim3(256), 0, st, d_calls.p, 1, T.perm.p, T.in_aabb.p, d_out.p, keys.p);
+                CK(hipGetLastError());
+            }
+            hipLaunchKernelGGL(k_sort_seed, dim3(1), dim3(1), 0, st, n_in, fixed_axis, ws.small.p, ws.counters.p, ws.big_a.p, ws.counters.p + 2);
             CK(hipGetLastError());
-            if (!device_sort(st, ws, d_calls.p, 1, n_in, (size_t)n_in, keys.p, T.perm.p, n_in, err)) return false;
+            if (!device_sort(st, ws, 0, any_big, (size_t)n_in, keys.p, T.in_aabb.p, T.perm.p, err)) return false;
+            CK(hipStreamSynchronize(st));  // c0 and o0 go out of scope
         }
 
         for (int depth = 0; !calls.empty(); depth++) {
@@ -1151,25 +1220,35 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
                 covered += (size_t)(calls[i].end - calls[i].begin);
             }
             const int ny = std::min(64, (longest + 1023) / 1024);  // blocks along a call's range in k_keys, k_bins, k_partition
-            if (!d_calls.alloc(nc) || !d_out.alloc(nc)) { err = "out of device memory"; return false; }
+            const bool sorts = T.type == 4, any_big = sorts && longest > SORT_BIG;
+            const int set = depth & 1;
+            if (!d_calls.alloc(nc) || !d_out.alloc(nc) || (sorts && !ws.reserve(covered, n_in, any_big))) { err = "out of device memory"; return false; }
             CK(hipMemcpyAsync(d_calls.p, hc.data(), sizeof(Call) * nc, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_list_box, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, T.in_kind.p, T.type, fixed_axis, d_out.p);
+            hipLaunchKernelGGL(k_list_box, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, T.in_kind.p, T.type, fixed_axis, d_out.p,
+                               sorts ? ws.small.p : nullptr, ws.big_a.p, ws.counters.p + set * SORT_COUNTERS, ws.counters.p + (set ^ 1) * SORT_COUNTERS);
             CK(hipGetLastError());
             std::vector<CallOut> ho(nc);
-            if (T.type == 4) {
-                hipLaunchKernelGGL(k_keys, dim3(nc, ny), dim3(256), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, d_out.p, keys.p);
-                CK(hipGetLastError());
-                if (!device_sort(st, ws, d_calls.p, nc, longest, covered, keys.p, T.perm.p, n_in, err)) return false;
+            if (sorts) {
+                if (any_big) {
+                    hipLaunchKernelGGL(k_keys, dim3(nc, ny), dim3(256), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, d_out.p, keys.p);
+                    CK(hipGetLastError());
+                }
+                if (!device_sort(st, ws, set, any_big, covered, keys.p, T.in_aabb.p, T.perm.p, err)) return false;
             }
             // bins and the stable partition follow on the device; the host only needs the outcome
             const bool at_limit = depth >= MAX_DEPTH_LIMIT;
-            if (!d_slices.alloc((size_t)nc * ny * 4 * MAXB)) { err = "out of device memory"; return false; }
-            hipLaunchKernelGGL(k_bins, dim3(nc, ny), dim3(256), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, T.order, at_limit ? 1 : 0, d_out.p, bins.p, d_slices.p);
-            CK(hipGetLastError());
-            hipLaunchKernelGGL(k_partition, dim3(nc, ny), dim3(256), 0, st, d_calls.p, nc, T.perm.p, tmp.p, d_out.p, bins.p, d_slices.p);
-            CK(hipGetLastError());
-            hipLaunchKernelGGL(k_partition_copy, dim3(nc, ny), dim3(256), 0, st, d_calls.p, nc, T.perm.p, tmp.p, d_out.p);
-            CK(hipGetLastError());
+            if (ny == 1) {
+                hipLaunchKernelGGL(k_bin_partition, dim3(nc), dim3(256), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, T.order, at_limit ? 1 : 0, d_out.p);
+                CK(hipGetLastError());
+            } else {
+                if (!d_slices.alloc((size_t)nc * ny * 4 * MAXB)) { err = "out of device memory"; return false; }
+                hipLaunchKernelGGL(k_bins, dim3(nc, ny), dim3(256), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, T.order, at_limit ? 1 : 0, d_out.p, bins.p, d_slices.p);
+                CK(hipGetLastError());
+                hipLaunchKernelGGL(k_partition, dim3(nc, ny), dim3(256), 0, st, d_calls.p, nc, T.perm.p, tmp.p, d_out.p, bins.p, d_slices.p);
+                CK(hipGetLastError());
+                hipLaunchKernelGGL(k_partition_copy, dim3(nc, ny), dim3(256), 0, st, d_calls.p, nc, T.perm.p, tmp.p, d_out.p);
+                CK(hipGetLastError());
+            }
             CK(hipMemcpyAsync(ho.data(), d_out.p, sizeof(CallOut) * nc, hipMemcpyDeviceToHost, st));
             CK(hipStreamSynchronize(st));
             std::vector<int> segc(nc, T.order);
