@@ -34,6 +34,33 @@ def test_sampled_filler_and_procedural_textures(pta, rd, rd_wf, golden_dir):
     _run_case(pta, rd, rd_wf, golden_dir, "textured", 320, 184, 6, 4, dispatches=2, scene=_textured_scene(pta))
 
 
+def test_missing_texture_texels_are_the_reference_bytes(pta, rd, rd_wf, golden_dir):
+    """ptk_texture_create(NULL) binds the filler grid: a white sphere sampling it shows exactly sky x (56,16,56,56)/255
+    and sky x (0,0,0,56)/255, the bytes of the reference's own test (test_utils.gd:5-11), on every schedule."""
+    import json
+    import os
+    from test_oracle_golden import check_missing_texture_image, missing_texture_scene
+    with open(os.path.join(golden_dir, "reference_vectors.json")) as f:
+        vectors = json.load(f)
+    wd = pta.work_dispatcher
+    scene = missing_texture_scene(pta)
+    packed = wd.pack_scene(scene, ob.OracleBvhBuilder(), 8)
+    w, h = 96, 64
+    counts = []
+    for dev in (rd, rd_wf):
+        d = wd.PTWorkDispatcher(dev)
+        d.create_buffers(w, h, packed=packed)
+        d.load_shader()
+        try:
+            win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=2, max_refraction_bounces=0)
+            win.frame = 0
+            d.create_compute_list(win, scene.camera, wd.sample_time(0), sync=True)
+            counts.append(check_missing_texture_image(dev.texture_get_data(d.image_buffer), vectors))
+        finally:
+            d.free_rids()
+    assert counts[0] == counts[1]
+
+
 def test_image_not_a_multiple_of_the_group(pta, rd, rd_wf, golden_dir):
     """100 x 60 pixels under 13 x 8 groups: invocations outside the image compute but never store."""
     wd = pta.work_dispatcher

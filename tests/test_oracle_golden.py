@@ -35,19 +35,60 @@ def test_merge_aabb_vectors(oracle, vectors):
         assert np.array_equal(out, _a6(case["out"])), case["msg"]
 
 
-def test_missing_texture_grid_rule(vectors):
-    """test_utils.gd:4-50: the 2x2 and 4x4 filler grids; the host mirror and both renderers use the same rule."""
+def missing_texture_scene(pta):
+    """One white sphere whose sampled texture has no image (PTWorkDispatcher binds the 8x8 filler grid for it,
+    pt_work_dispatcher.gd:350-370), seen in front of the sky."""
+    sc, gm = pta.scene, pta.godot_math
+    scene = sc.PTScene()
+    scene.add_object(sc.PTSphere(radius=1.0, material=sc.PTMaterial(albedo=(1.0, 1.0, 1.0)), texture=sc.PTSampledTexture(image=None)))
+    scene.camera = sc.PTCamera(transform=gm.Transform3D.looking_at((0.0, 0.0, 3.0), (0.0, 0.0, 0.0)), fov=50.0)
+    return scene
+
+
+def missing_texture_pixel_values(vectors):
+    """The only three values a pixel of missing_texture_scene can take at depth 2, frame 0: sky, or sky times one
+    of the two filler texels.  The texel bytes are the reference's (test_utils.gd:5-11: 56,16,56,56 and 0,0,0,56,
+    DATA_FORMAT_R8G8B8A8_UNORM, i.e. byte / 255); the path multiplies 1 by (albedo 1 * texel), then by the sky
+    colour (0.7, 0.7, 0.9, 1) of the second ray, which always leaves a convex object."""
     g = vectors["missing_texture_grid"]
+    sky = np.array([0.7, 0.7, 0.9, 1.0], np.float32)
+    unorm = lambda b: (np.array(b, np.float32) / np.float32(255.0)).astype(np.float32)
+    return sky, (unorm(g["pink"]) * sky).astype(np.float32), (unorm(g["black"]) * sky).astype(np.float32)
 
-    def grid(n):
-        out = []
-        for i in range(n):
-            for j in range(n):
-                out += g["pink"] if ((i % 2) + (j % 2)) % 2 == 0 else g["black"]
-        return out
 
-    assert grid(2) == g["pink"] + g["black"] + g["black"] + g["pink"]
-    assert len(grid(4)) == 64 and grid(4)[:8] == g["pink"] + g["black"]
+def check_missing_texture_image(img, vectors):
+    """The stored pixel is the path's colour with the shader's gamma (rgb ** camera.gamma, 1 / 2.2 by default, ray_tracer.comp:1682-1683;
+    alpha as it is).  The power goes through the renderer's own pow, so rgb is compared within 2e-6 (and the
+    image may hold three distinct values only); alpha, a plain byte / 255, bit for bit."""
+    sky, pink, black = missing_texture_pixel_values(vectors)
+    flat = img.reshape(-1, 4)
+    assert np.unique(flat, axis=0).shape[0] == 3, "exactly three colours: sky and the two texels"
+
+    def matches(v):
+        rgb = np.power(v[:3].astype(np.float64), 1.0 / 2.2)
+        return (np.abs(flat[:, :3] - rgb) <= 2e-6).all(1) & (flat[:, 3].view(np.uint32) == v[3:].view(np.uint32)[0])
+
+    is_sky, is_pink, is_black = matches(sky), matches(pink), matches(black)
+    assert (is_sky | is_pink | is_black).all(), f"{int((~(is_sky | is_pink | is_black)).sum())} pixels are none of sky / pink texel / black texel"
+    # the sphere covers about a quarter of the frame; the 8x8 grid over (u, v) shows both texels in quantity
+    assert is_pink.sum() > flat.shape[0] // 20 and is_black.sum() > flat.shape[0] // 20 and is_sky.sum() > flat.shape[0] // 4
+    return int(is_pink.sum()), int(is_black.sum())
+
+
+def test_missing_texture_texels_through_the_oracle(pta, vectors):
+    """test_utils.gd:4-50 pins the filler grid's bytes and its parity rule (pink where (i%2 + j%2) % 2 == 0); here
+    the oracle renders an object that samples it and every pixel must carry exactly those bytes."""
+    g = vectors["missing_texture_grid"]
+    assert g["pink"] == [56, 16, 56, 56] and g["black"] == [0, 0, 0, 56]
+    wd = pta.work_dispatcher
+    scene = missing_texture_scene(pta)
+    packed = wd.pack_scene(scene, ob.OracleBvhBuilder(), 8)
+    w, h = 96, 64
+    img = np.zeros((h, w, 4), np.float32)
+    win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=2, max_refraction_bounces=0)
+    win.frame = 0
+    ob.render(packed, wd.push_constant_bytes(scene.camera, win, wd.sample_time(0)), img, w // 8, h // 8)
+    check_missing_texture_image(img, vectors)
 
 
 # ---- the three hand-built trees -----------------------------------------------------------
