@@ -309,6 +309,51 @@ def main():
     if tile_partition is not None:
         out["tile_partition"] = tile_partition
 
+    if world == 1:
+        # Beside the contract's figure (the tree the plugin's own builder rule produces): the same frames over the
+        # library's binned-SAH tree, which a host may ask ptk_bvh_build for instead.  Not part of `value`.
+        try:
+            disp2 = wd.PTWorkDispatcher(rd)
+            disp2.set_scene(scene)
+            for m in scene.meshes:
+                m.bvh_type = pta.scene.BVH_SAH
+            t0 = time.time()
+            disp2.create_buffers(WIDTH, HEIGHT, order=8, bvh_type=pta.scene.BVH_SAH)
+            sah_build_s = time.time() - t0
+            disp2.load_shader(refraction_mode=2, use_emission=False, early_t_break=False)
+            rd.set_renderer(pta.rendering_device.PTK_RENDERER_AUTO)
+            rd.trace_enable(pta.rendering_device.PTK_TRACE_COUNTERS)
+            c2 = np.zeros(pta.rendering_device.PTK_NCOUNTERS, dtype=np.int64)
+            for k in range(args.steps):
+                win.frame = k
+                disp2.create_compute_list(win, scene.camera, wd.sample_time(k), sync=True)
+                c2 += rd.trace_read_counters(disp2.image_buffer).reshape(-1, pta.rendering_device.PTK_NCOUNTERS).sum(0)
+            rd.trace_enable(0)
+            rd.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
+            cnt2 = dict(zip(pta.rendering_device.COUNTER_NAMES, c2.tolist()))
+
+            def run_sah(n):
+                for k in range(n):
+                    win.frame = k
+                    disp2.create_compute_list(win, scene.camera, wd.sample_time(k))
+                rd.sync()
+
+            run_sah(args.warmup)
+            t_sah = time.perf_counter()
+            run_sah(args.steps)
+            sah_s = time.perf_counter() - t_sah
+            out["sah_tree"] = {"value": cnt2["rays"] / sah_s / 1e6, "unit": "Mrays/s", "ms_per_step": sah_s / args.steps * 1e3,
+                               "bvh_nodes": len(disp2.packed.bvh) // 32, "bvh_build_s": sah_build_s,
+                               "box_tests_per_ray": cnt2["box_tests"] / max(cnt2["rays"], 1),
+                               "box_tests_per_ray_reference_rule_tree": cnt["box_tests"] / max(cnt["rays"], 1),
+                               "note": "same scene, camera and samples over the binned-SAH tree (BVH type 5 of ptk_bvh_build); an extra, not the contract's workload"}
+            disp2.free_rids()
+        except Exception as exc:  # noqa: BLE001
+            out["sah_tree"] = {"error": repr(exc)}
+        finally:
+            for m in scene.meshes:
+                m.bvh_type = pta.scene.BVH_XYZ_SORTED
+
     if not args.no_cpu_baseline and world == 1:
         # CPU baseline: the oracle (a restatement of ray_tracer.comp, not Godot/lavapipe, which do not
         # exist on this box) renders ONE full-frame dispatch of the same workload on the host cores.
