@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
+    ap.add_argument("--sah-tree", action="store_true", help="after the timed region, also time the same frames over the binned-SAH tree (field sah_tree)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -309,7 +310,7 @@ def main():
     if tile_partition is not None:
         out["tile_partition"] = tile_partition
 
-    if world == 1:
+    if world == 1 and args.sah_tree:
         # Beside the contract's figure (the tree the plugin's own builder rule produces): the same frames over the
         # library's binned-SAH tree, which a host may ask ptk_bvh_build for instead.  Not part of `value`.
         try:
