@@ -43,6 +43,7 @@ class TimedBuilder:
 
 def scenes(golden):
     yield "sphere_scene1 (6 spheres)", pta.scenes.load_fixture_scene("sphere_scene1", golden)
+    yield "benchmark_random_scene (487 spheres)", pta.scenes.load_fixture_scene("benchmark_random_scene", golden)
     yield "random spheres (grid 32)", pta.scenes.random_spheres_scene(grid=32, seed=5)
     yield "dragon mesh (fixture)", pta.scenes.load_fixture_scene("dragon_test", golden)
     yield "atrium (262144 triangles)", pta.scenes.atrium_scene(262144, seed=7)
@@ -84,7 +85,7 @@ def main():
                 cpu_ms = tc.ms
             rows.append({"scene": name, "type": type_name, "nodes": nodes, "gpu_build_ms": round(best_build, 3),
                          "gpu_bind_ms": round(best_bind, 3), "cpu_oracle_build_ms": None if cpu_ms is None else round(cpu_ms, 2)})
-            print("%-28s %-28s nodes %7d  build %8.3f ms  bind %7.3f ms  cpu %s" % (
+            print("%-38s %-28s nodes %7d  build %8.3f ms  bind %7.3f ms  cpu %s" % (
                 name, type_name, nodes, best_build, best_bind, "-" if cpu_ms is None else "%.1f ms" % cpu_ms), flush=True)
         for m, t in zip(scene.meshes, mesh_types):
             m.bvh_type = t
