@@ -159,6 +159,74 @@ PackedInt32Array PtkRenderingDevice::bvh_get_object_ids(int64_t bvh) {
     return out;
 }
 
+PackedInt64Array PtkRenderingDevice::bvh_bind(int64_t bvh) {
+    PackedInt64Array out;
+    ERR_FAIL_NULL_V(ctx, out);
+    uint64_t nodes = 0, ids = 0;
+    if (check(ptk_bvh_bind(ctx, (uint64_t)bvh, &nodes, &ids), "bvh_bind") != PTK_OK) return out;
+    out.push_back((int64_t)nodes);
+    out.push_back((int64_t)ids);
+    return out;
+}
+
+int PtkRenderingDevice::bvh_refit(const PackedInt32Array& object_ids, const PackedFloat32Array& values12) {
+    ERR_FAIL_NULL_V(ctx, -PTK_E_STATE);
+    ERR_FAIL_COND_V(values12.size() != object_ids.size() * 12, -PTK_E_INVALID);
+    std::vector<ptk_refit_event> events((size_t)object_ids.size());
+    for (int64_t i = 0; i < object_ids.size(); i++) {
+        events[(size_t)i].object_id = object_ids[i];
+        for (int k = 0; k < 12; k++) events[(size_t)i].v[k] = values12[i * 12 + k];
+    }
+    int32_t updated = 0;
+    const int rc = check(ptk_bvh_refit(ctx, events.data(), (int)events.size(), &updated), "bvh_refit");
+    return rc == PTK_OK ? updated : -rc;
+}
+
+Dictionary PtkRenderingDevice::mesh_to_triangles(const Dictionary& surface, const Transform3D& transform, int material_index,
+                                                 int64_t texture_id) {
+    Dictionary out;
+    ERR_FAIL_NULL_V(ctx, out);
+    // keys of RenderingServer.mesh_get_surface (servers/rendering_server.cpp, Godot 4.3)
+    const PackedByteArray vertex = surface.get("vertex_data", PackedByteArray());
+    const PackedByteArray attribute = surface.get("attribute_data", PackedByteArray());
+    const PackedByteArray index = surface.get("index_data", PackedByteArray());
+    const AABB box = surface.get("aabb", AABB());
+    const Vector4 uv_scale = surface.get("uv_scale", Vector4());
+    ptk_mesh_surface s = {};
+    s.format = (uint64_t)(int64_t)surface.get("format", 0);
+    s.vertex_count = (int32_t)(int64_t)surface.get("vertex_count", 0);
+    s.index_count = (int32_t)(int64_t)surface.get("index_count", 0);
+    s.vertex_data = vertex.ptr(); s.vertex_bytes = (size_t)vertex.size();
+    s.attribute_data = attribute.size() ? attribute.ptr() : nullptr; s.attribute_bytes = (size_t)attribute.size();
+    s.index_data = index.ptr(); s.index_bytes = (size_t)index.size();
+    s.aabb[0] = box.position.x; s.aabb[1] = box.position.y; s.aabb[2] = box.position.z;
+    s.aabb[3] = box.size.x; s.aabb[4] = box.size.y; s.aabb[5] = box.size.z;
+    s.uv_scale[0] = uv_scale.x; s.uv_scale[1] = uv_scale.y; s.uv_scale[2] = uv_scale.z; s.uv_scale[3] = uv_scale.w;
+    const Basis& b = transform.basis;
+    const float t12[12] = {b.rows[0].x, b.rows[0].y, b.rows[0].z, b.rows[1].x, b.rows[1].y, b.rows[1].z,
+                           b.rows[2].x, b.rows[2].y, b.rows[2].z, transform.origin.x, transform.origin.y, transform.origin.z};
+    const int64_t n = s.index_count / 3;
+    PackedByteArray records;
+    PackedFloat32Array aabbs, uvs;
+    records.resize(n * 80);
+    aabbs.resize(n * 6);
+    uvs.resize(n * 6);
+    int32_t n_triangles = 0;
+    if (check(ptk_mesh_to_triangles(ctx, &s, t12, material_index, (uint32_t)texture_id, records.ptrw(), aabbs.ptrw(), uvs.ptrw(), &n_triangles),
+              "mesh_to_triangles") != PTK_OK)
+        return out;
+    out["records"] = records;
+    out["aabbs"] = aabbs;
+    out["uvs"] = uvs;
+    out["triangles"] = n_triangles;
+    return out;
+}
+
+int PtkRenderingDevice::set_option(int option, int value) {
+    ERR_FAIL_NULL_V(ctx, PTK_E_STATE);
+    return check(ptk_set_option(ctx, option, value), "set_option");
+}
+
 int PtkRenderingDevice::set_renderer(int renderer) {
     ERR_FAIL_NULL_V(ctx, PTK_E_STATE);
     return check(ptk_set_renderer(ctx, renderer), "set_renderer");
@@ -195,11 +263,19 @@ void PtkRenderingDevice::_bind_methods() {
                          &PtkRenderingDevice::bvh_build);
     ClassDB::bind_method(D_METHOD("bvh_get_nodes", "bvh"), &PtkRenderingDevice::bvh_get_nodes);
     ClassDB::bind_method(D_METHOD("bvh_get_object_ids", "bvh"), &PtkRenderingDevice::bvh_get_object_ids);
+    ClassDB::bind_method(D_METHOD("bvh_bind", "bvh"), &PtkRenderingDevice::bvh_bind);
+    ClassDB::bind_method(D_METHOD("bvh_refit", "object_ids", "values12"), &PtkRenderingDevice::bvh_refit);
+    ClassDB::bind_method(D_METHOD("mesh_to_triangles", "surface", "transform", "material_index", "texture_id"),
+                         &PtkRenderingDevice::mesh_to_triangles);
+    ClassDB::bind_method(D_METHOD("set_option", "option", "value"), &PtkRenderingDevice::set_option);
     ClassDB::bind_method(D_METHOD("set_renderer", "renderer"), &PtkRenderingDevice::set_renderer);
     ClassDB::bind_method(D_METHOD("last_dispatch_ms"), &PtkRenderingDevice::last_dispatch_ms);
     BIND_CONSTANT(PTK_DISPLAY_STORED);
     BIND_CONSTANT(PTK_DISPLAY_CANVAS);
     BIND_CONSTANT(PTK_DISPLAY_CANVAS_SRGB);
+    BIND_CONSTANT(PTK_REFIT_MESH);
+    BIND_CONSTANT(PTK_OPT_TRIANGLE_UVS);
+    BIND_CONSTANT(PTK_BVH_SAH);
     BIND_CONSTANT(PTK_RENDERER_AUTO);
     BIND_CONSTANT(PTK_RENDERER_SINGLE_KERNEL);
     BIND_CONSTANT(PTK_RENDERER_WAVEFRONT);

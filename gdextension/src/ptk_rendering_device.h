@@ -15,12 +15,14 @@
 #include <godot_cpp/classes/image_texture.hpp>
 #include <godot_cpp/classes/ref_counted.hpp>
 #include <godot_cpp/core/class_db.hpp>
+#include <godot_cpp/variant/dictionary.hpp>
 #include <godot_cpp/variant/packed_byte_array.hpp>
 #include <godot_cpp/variant/packed_float32_array.hpp>
 #include <godot_cpp/variant/packed_int32_array.hpp>
 #include <godot_cpp/variant/packed_int64_array.hpp>
 #include <godot_cpp/variant/packed_string_array.hpp>
 #include <godot_cpp/variant/string.hpp>
+#include <godot_cpp/variant/transform3d.hpp>
 
 #include <vector>
 
@@ -74,6 +76,20 @@ public:
                       const PackedInt64Array& mesh_bvhs, const PackedFloat32Array& mesh_transforms12, const PackedInt32Array& mesh_indices);
     PackedByteArray bvh_get_nodes(int64_t bvh);
     PackedInt32Array bvh_get_object_ids(int64_t bvh);
+    // create_object_id_buffer + create_bvh_buffer for a tree built here (pt_work_dispatcher.gd:184-185,723-758):
+    // returns [nodes buffer, object-id buffer], bound at (3,0) and (3,1) without a trip through host memory
+    PackedInt64Array bvh_bind(int64_t bvh);
+    // PTBVHTree.update_aabb chains + the dirty-node uploads of pt_renderer.gd:771-788 for the bound tree.
+    // object_ids[i] with values12[12*i .. 12*i+5] = the object's new box (position, size), or
+    // mesh index | PTK_REFIT_MESH << 24 with the mesh's new Transform3D (basis rows, origin).  Returns the number of
+    // nodes rewritten, or a negative error code.
+    int bvh_refit(const PackedInt32Array& object_ids, const PackedFloat32Array& values12);
+
+    // PTObjectContainer.mesh_to_pttriangles on the GPU (pt_object_container.gd:163-186): `surface` is the dictionary
+    // of RenderingServer.mesh_get_surface(mesh.get_rid(), 0).  Returns {"records": PackedByteArray (80 B per triangle),
+    // "aabbs": PackedFloat32Array (6 per triangle), "uvs": PackedFloat32Array (6 per triangle)}.
+    Dictionary mesh_to_triangles(const Dictionary& surface, const Transform3D& transform, int material_index, int64_t texture_id);
+    int set_option(int option, int value);
 
     int set_renderer(int renderer);
     float last_dispatch_ms();
