@@ -356,6 +356,82 @@ class PTWorkDispatcher:
         for slot, img in enumerate(packed.sampled_textures):
             self.rids_to_free.append(self.rd.texture_create(slot, img))
         self.transform_buffer = self._create_uniform(packed.transforms, TRANSFORM_SET_INDEX, TRANSFORM_BIND)
+        # record counts the buffers hold (pt_work_dispatcher.gd:56-63)
+        self.material_buffer_size = len(packed.materials) // 64
+        self.sphere_buffer_size = len(packed.spheres) // 32
+        self.plane_buffer_size = len(packed.planes) // 32
+        # (the triangle buffer's padding is 32 bytes per missing record, :717-718, so its byte length does not give the count)
+        self.triangle_buffer_size = ceil_snap(self._scene.n_triangles, TRIANGLE_COUNT_STEP) if self._scene is not None else len(packed.triangles) // 80
+        self.bvh_buffer_size = len(packed.bvh) // NODE_BYTE_SIZE
+
+    # ---- buffer growth (pt_work_dispatcher.gd:511-637) --------------------------------------------------
+    def _replace_uniform(self, old: int, data: bytes, set_index: int, binding: int) -> int:
+        """free_rid + create_*_buffer + uniform_set_create: the new buffer takes the old one's binding."""
+        if old in self.rids_to_free:
+            self.rids_to_free.remove(old)
+        self.rd.free_rid(old)
+        return self._create_uniform(data, set_index, binding)
+
+    def expand_object_buffer(self, object_type: int, steps: int = 0) -> bool:
+        """Grows one object buffer to fit the scene (steps < 1) or by `steps` count steps, refilled from the
+        scene's current objects; False when it already fits (:511-567)."""
+        scn = self._scene
+        table = {
+            sc.SPHERE: ("sphere_buffer", "sphere_buffer_size", len(scn.spheres), SPHERE_COUNT_STEP, create_spheres_byte_array, SPHERES_BIND),
+            sc.PLANE: ("plane_buffer", "plane_buffer_size", len(scn.planes), PLANE_COUNT_STEP, create_planes_byte_array, PLANES_BIND),
+            sc.TRIANGLE: ("triangle_buffer", "triangle_buffer_size", scn.n_triangles, TRIANGLE_COUNT_STEP,
+                          create_triangles_byte_array, TRIANGLES_BIND),
+        }
+        if object_type not in table:
+            return False
+        buf, size_name, count, step, packer, binding = table[object_type]
+        size = getattr(self, size_name)
+        if steps < 1:
+            if size >= count:
+                return False
+            new_size = ceil_snap(count, step)
+            if new_size <= size:
+                return False
+        else:
+            new_size = size + step * steps
+        setattr(self, size_name, new_size)
+        setattr(self, buf, self._replace_uniform(getattr(self, buf), packer(scn, new_size), OBJECT_SET_INDEX, binding))
+        return True
+
+    def check_object_buffer_size(self) -> bool:
+        """Expands every object buffer the scene has outgrown (:570-581)."""
+        grown = False
+        for t in (sc.SPHERE, sc.PLANE, sc.TRIANGLE):
+            grown = self.expand_object_buffer(t) or grown
+        return grown
+
+    def expand_material_buffer(self, steps: int = 0) -> bool:
+        scn = self._scene
+        if steps < 1:
+            if self.material_buffer_size >= len(scn.materials):
+                return False
+            new_size = ceil_snap(len(scn.materials), MATERIAL_COUNT_STEP)
+            if new_size <= self.material_buffer_size:
+                return False
+        else:
+            new_size = self.material_buffer_size + MATERIAL_COUNT_STEP * steps
+        self.material_buffer_size = new_size
+        self.material_buffer = self._replace_uniform(self.material_buffer, create_materials_byte_array(scn, new_size), OBJECT_SET_INDEX, MATERIALS_BIND)
+        return True
+
+    def expand_bvh_buffer(self, node_bytes: bytes, object_ids, steps: int = 0) -> bool:
+        """Grows the node buffer for a tree that no longer fits (:584-603) and refills it and the id table from the
+        given tree; with a tree that still fits, both are rewritten in place."""
+        n = len(node_bytes) // NODE_BYTE_SIZE
+        grow = steps >= 1 or self.bvh_buffer_size < n
+        if grow:
+            self.bvh_buffer_size = self.bvh_buffer_size + BVH_COUNT_STEP * steps if steps >= 1 else ceil_snap(n, BVH_COUNT_STEP)
+            self.bvh_buffer = self._replace_uniform(self.bvh_buffer, create_bvh_byte_array(node_bytes, self.bvh_buffer_size), BVH_SET_INDEX, BVH_BIND)
+        else:
+            data = create_bvh_byte_array(node_bytes, self.bvh_buffer_size)
+            self.rd.buffer_update(self.bvh_buffer, 0, len(data), data)
+        self.object_id_buffer = self._replace_uniform(self.object_id_buffer, create_object_id_byte_array(object_ids), BVH_SET_INDEX, OBJECT_ID_BIND)
+        return grow
 
     def create_compute_list(self, window: PTRenderWindow, camera: Optional[sc.PTCamera] = None, time: float = 0.0,
                             sync: bool = False):

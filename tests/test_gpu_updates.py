@@ -106,3 +106,57 @@ def test_edits_between_samples(pta, rd, rd_wf, golden_dir, scene_name):
         rd.set_renderer(pta.rendering_device.PTK_RENDERER_AUTO)
         for _, _, d in devs:
             d.free_rids()
+
+
+def test_buffers_grow_with_the_scene(pta, golden_dir):
+    """PTWorkDispatcher.expand_object_buffer / expand_material_buffer / expand_bvh_buffer
+    (pt_work_dispatcher.gd:511-637): objects and materials are added until every buffer's count step is crossed;
+    the grown buffers take the old ones' bindings, the new tree replaces the old one, and the image equals the
+    oracle's render of the freshly packed scene."""
+    wd, sc, gm = pta.work_dispatcher, pta.scene, pta.godot_math
+    scene = pta.scenes.load_fixture_scene("sphere_scene1", golden_dir)
+    w, h = 160, 96
+    dev = pta.PtkRenderingDevice(0)
+    try:
+        disp = wd.PTWorkDispatcher(dev)
+        disp.set_scene(scene)
+        disp.create_buffers(w, h)
+        disp.load_shader()
+        before = (disp.sphere_buffer_size, disp.plane_buffer_size, disp.triangle_buffer_size, disp.material_buffer_size, disp.bvh_buffer_size)
+        assert not disp.check_object_buffer_size() and not disp.expand_material_buffer(), "a scene that fits grows nothing"
+        rng = np.random.default_rng(23)
+        mats = [sc.PTMaterial(albedo=tuple(rng.uniform(0.2, 0.9, 3).tolist()), metallic=float(rng.random() > 0.7)) for _ in range(20)]
+        for i in range(70):  # past one sphere step (64)
+            scene.add_object(sc.PTSphere(transform=gm.Transform3D(origin=tuple(rng.uniform(-4.0, 4.0, 3).tolist())), radius=0.25, material=mats[i % 20]))
+        for i in range(18):  # past one triangle step (16)
+            p = rng.uniform(-3.0, 3.0, 3)
+            scene.add_object(sc.PTTriangle(vertex1=tuple(p.tolist()), vertex2=tuple((p + [0.8, 0.0, 0.1]).tolist()), vertex3=tuple((p + [0.1, 0.9, 0.0]).tolist()), material=mats[i % 20]))
+        for i in range(17):  # past one plane step (16)
+            scene.add_object(sc.PTPlane(normal=(0.0, 1.0, 0.0), distance=-6.0 - i, material=mats[i % 20]))
+        assert disp.check_object_buffer_size()
+        assert disp.expand_material_buffer()
+        nodes, ids = wd.create_scene_bvh(scene, wd.DeviceBvhBuilder(dev), 8)
+        assert not disp.expand_bvh_buffer(nodes, ids), "the new tree (about 20 nodes) still fits the 64-node buffer: rewritten in place"
+        after = (disp.sphere_buffer_size, disp.plane_buffer_size, disp.triangle_buffer_size, disp.material_buffer_size, disp.bvh_buffer_size)
+        assert all(a > b for a, b in zip(after[:4], before[:4])) and after[4] == before[4], (before, after)
+        assert not disp.check_object_buffer_size(), "second call: everything fits"
+        packed = wd.pack_scene(scene, ob.OracleBvhBuilder(), 8)
+        cpu = np.zeros((h, w, 4), np.float32)
+        for k in range(2):
+            win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=4)
+            win.frame = k
+            t = wd.sample_time(k)
+            ob.render(packed, wd.push_constant_bytes(scene.camera, win, t), cpu, w // 8, h // 8, trace=False)
+            disp.create_compute_list(win, scene.camera, t, sync=True)
+            _compare_image(f"grown[{k}]", dev.texture_get_data(disp.image_buffer), cpu)
+        # growing by explicit steps keeps the contents
+        assert disp.expand_object_buffer(sc.SPHERE, steps=2) and disp.sphere_buffer_size == after[0] + 128
+        assert disp.expand_bvh_buffer(nodes, ids, steps=1) and disp.bvh_buffer_size == after[4] + 64
+        win.frame = 2
+        t = wd.sample_time(2)
+        ob.render(packed, wd.push_constant_bytes(scene.camera, win, t), cpu, w // 8, h // 8, trace=False)
+        disp.create_compute_list(win, scene.camera, t, sync=True)
+        _compare_image("grown by steps", dev.texture_get_data(disp.image_buffer), cpu)
+        disp.free_rids()
+    finally:
+        dev.close()
