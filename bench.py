@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
+    ap.add_argument("--c-abi-comm", action="store_true",
+                    help="N > 1: after the timed region, repeat the batch with the reduce done by libptk's own RCCL calls (field c_abi_comm)")
     ap.add_argument("--sah-tree", action="store_true", help="after the timed region, also time the same frames over the binned-SAH tree (field sah_tree)")
     args = ap.parse_args()
 
@@ -238,6 +240,35 @@ def main():
         except Exception as exc:  # noqa: BLE001
             tile_partition = {"error": repr(exc)}
 
+    # Opt-in: the same batch with the reduce issued through the C ABI (ptk_comm_init / ptk_image_reduce_mean), the
+    # path of a host without torch.distributed.  The unique id travels over the existing process group.
+    c_abi_comm = None
+    if world > 1 and args.c_abi_comm and not rehearsal:
+        try:
+            ids = [pta.PtkRenderingDevice.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            rd.comm_init(world, rank, ids[0])
+
+            def run_c_abi(n):
+                for k in range(n):
+                    win.frame = first_frame + k
+                    disp.create_compute_list(win, scene.camera, wd.sample_time(sample_index(k)))
+                rd.image_reduce_mean(disp.image_buffer, 0)
+
+            run_c_abi(1)
+            barrier()
+            t_c = time.perf_counter()
+            run_c_abi(args.steps)
+            barrier()
+            c_s = time.perf_counter() - t_c
+            tc = torch.tensor([c_s], dtype=torch.float64, device=f"cuda:{device_index}")
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            c_abi_comm = {"ms_per_step": float(tc[0].item()) / args.steps * 1e3, "steps": args.steps,
+                          "note": "sample batches with ptk_image_reduce_mean (RCCL called by libptk) instead of torch.distributed"}
+            rd.comm_destroy()
+        except Exception as exc:  # noqa: BLE001
+            c_abi_comm = {"error": repr(exc)}
+
     rays_total = rays_local
     if world > 1:
         t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=f"cuda:{device_index}")
@@ -309,6 +340,8 @@ def main():
 
     if tile_partition is not None:
         out["tile_partition"] = tile_partition
+    if c_abi_comm is not None:
+        out["c_abi_comm"] = c_abi_comm
 
     if world == 1 and args.sah_tree:
         # Beside the contract's figure (the tree the plugin's own builder rule produces): the same frames over the

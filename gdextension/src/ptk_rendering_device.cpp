@@ -227,6 +227,38 @@ int PtkRenderingDevice::set_option(int option, int value) {
     return check(ptk_set_option(ctx, option, value), "set_option");
 }
 
+PackedByteArray PtkRenderingDevice::comm_unique_id() {
+    PackedByteArray id;
+    id.resize(PTK_COMM_ID_BYTES);
+    if (ptk_comm_unique_id(id.ptrw()) != PTK_OK) {
+        ERR_PRINT(String("PT: comm_unique_id failed: ") + ptk_last_error(nullptr));
+        id.clear();
+    }
+    return id;
+}
+
+int PtkRenderingDevice::comm_init(int world, int rank, const PackedByteArray& unique_id) {
+    ERR_FAIL_NULL_V(ctx, PTK_E_STATE);
+    ERR_FAIL_COND_V(unique_id.size() != PTK_COMM_ID_BYTES, PTK_E_INVALID);
+    return check(ptk_comm_init(ctx, world, rank, unique_id.ptr()), "comm_init");
+}
+
+int PtkRenderingDevice::image_reduce_mean(int64_t image, int root) {
+    ERR_FAIL_NULL_V(ctx, PTK_E_STATE);
+    return check(ptk_image_reduce_mean(ctx, (uint64_t)image, root), "image_reduce_mean");
+}
+
+int PtkRenderingDevice::image_gather_bands(int64_t image, const PackedInt32Array& first_row, const PackedInt32Array& n_rows, int root) {
+    ERR_FAIL_NULL_V(ctx, PTK_E_STATE);
+    ERR_FAIL_COND_V(first_row.size() != n_rows.size(), PTK_E_INVALID);
+    return check(ptk_image_gather_bands(ctx, (uint64_t)image, first_row.ptr(), n_rows.ptr(), root), "image_gather_bands");
+}
+
+int PtkRenderingDevice::comm_destroy() {
+    ERR_FAIL_NULL_V(ctx, PTK_E_STATE);
+    return check(ptk_comm_destroy(ctx), "comm_destroy");
+}
+
 int PtkRenderingDevice::set_renderer(int renderer) {
     ERR_FAIL_NULL_V(ctx, PTK_E_STATE);
     return check(ptk_set_renderer(ctx, renderer), "set_renderer");
@@ -268,6 +300,11 @@ void PtkRenderingDevice::_bind_methods() {
     ClassDB::bind_method(D_METHOD("mesh_to_triangles", "surface", "transform", "material_index", "texture_id"),
                          &PtkRenderingDevice::mesh_to_triangles);
     ClassDB::bind_method(D_METHOD("set_option", "option", "value"), &PtkRenderingDevice::set_option);
+    ClassDB::bind_static_method("PtkRenderingDevice", D_METHOD("comm_unique_id"), &PtkRenderingDevice::comm_unique_id);
+    ClassDB::bind_method(D_METHOD("comm_init", "world", "rank", "unique_id"), &PtkRenderingDevice::comm_init);
+    ClassDB::bind_method(D_METHOD("image_reduce_mean", "image", "root"), &PtkRenderingDevice::image_reduce_mean);
+    ClassDB::bind_method(D_METHOD("image_gather_bands", "image", "first_row", "n_rows", "root"), &PtkRenderingDevice::image_gather_bands);
+    ClassDB::bind_method(D_METHOD("comm_destroy"), &PtkRenderingDevice::comm_destroy);
     ClassDB::bind_method(D_METHOD("set_renderer", "renderer"), &PtkRenderingDevice::set_renderer);
     ClassDB::bind_method(D_METHOD("last_dispatch_ms"), &PtkRenderingDevice::last_dispatch_ms);
     BIND_CONSTANT(PTK_DISPLAY_STORED);

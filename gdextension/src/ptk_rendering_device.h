@@ -91,6 +91,13 @@ public:
     Dictionary mesh_to_triangles(const Dictionary& surface, const Transform3D& transform, int material_index, int64_t texture_id);
     int set_option(int option, int value);
 
+    // several GPUs of one node, one PtkRenderingDevice per process: RCCL through libptk
+    static PackedByteArray comm_unique_id();  // made on rank 0, 128 bytes, handed to every rank by the host
+    int comm_init(int world, int rank, const PackedByteArray& unique_id);
+    int image_reduce_mean(int64_t image, int root);
+    int image_gather_bands(int64_t image, const PackedInt32Array& first_row, const PackedInt32Array& n_rows, int root);
+    int comm_destroy();
+
     int set_renderer(int renderer);
     float last_dispatch_ms();
 };

@@ -258,6 +258,26 @@ int ptk_update_stats(ptk_ctx* ctx, long long* full_validations, long long* patch
  * (e.g. the torch tensor handed to an RCCL reduce / gather), without a trip through host memory. */
 int ptk_image_copy_device(ptk_ctx* ctx, uint64_t image, void* device_ptr, size_t nbytes, int to_image);
 
+/* Combining the per-GPU images of one node over RCCL, for hosts without torch.distributed; no counterpart in the
+ * reference, which renders on one device.  One context per GPU, one process (or thread) per context; RCCL is
+ * loaded at the first ptk_comm_* call (librccl.so), so a single-GPU host never needs it.
+ *   ptk_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means
+ *   ptk_comm_init        every rank joins (ncclCommInitRank on the context's GPU); collective
+ *   ptk_image_reduce_mean   sample batches: every rank holds the running mean of its own samples (frame numbers
+ *                        from 1, so that none is overwritten); afterwards root's image is the mean over ranks
+ *                        (sum, then * 1/world); the other ranks' images are left as they were
+ *   ptk_image_gather_bands  tile rows: rank r has rendered rows [first_row[r], first_row[r] + n_rows[r]) of the
+ *                        image (multiples of 8 from the group counts and image_offset_y it dispatched with);
+ *                        afterwards root's image holds every band, bit for bit
+ *   ptk_comm_destroy     leaves the communicator (ptk_destroy does it too)
+ * All collectives run on the context's stream, ordered after its dispatches, and return when they have ended. */
+enum { PTK_COMM_ID_BYTES = 128 };
+int ptk_comm_unique_id(void* id128);
+int ptk_comm_init(ptk_ctx* ctx, int world, int rank, const void* id128);
+int ptk_image_reduce_mean(ptk_ctx* ctx, uint64_t image, int root);
+int ptk_image_gather_bands(ptk_ctx* ctx, uint64_t image, const int32_t* first_row, const int32_t* n_rows, int root);
+int ptk_comm_destroy(ptk_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

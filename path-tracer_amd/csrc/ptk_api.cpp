@@ -3,6 +3,7 @@
 // Serves the calls the reference's PTWorkDispatcher / PTRenderer make on
 // Godot's RenderingDevice (proprietary_dataclasses/pt_work_dispatcher.gd,
 // pt_renderer.gd); see include/ptk.h for the call-by-call mapping.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -13,6 +14,7 @@
 #include <cstdlib>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -59,6 +61,8 @@ struct ptk_ctx {
     std::map<std::pair<int, int>, uint64_t> bound;  // (set, binding) -> buffer handle
     uint64_t image = 0;
     std::unique_ptr<BoundTree> bound_tree;
+    void* comm = nullptr;  // ncclComm_t of ptk_comm_init
+    int comm_world = 0, comm_rank = -1;
     bool in_refit = false;  // the library's own node updates do not invalidate the bound tree
     std::map<int, uint64_t> texture_slots;
     // configuration (ptk_configure)
@@ -229,6 +233,7 @@ void ptk_destroy(ptk_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)ptk_comm_destroy(ctx);
     for (auto& kv : ctx->objects) release(ctx, kv.second.get());
     ctx->objects.clear();
     if (ctx->d_live_planes) (void)hipFree(ctx->d_live_planes);
@@ -1618,3 +1623,140 @@ int ptk_bvh_read(ptk_ctx* ctx, uint64_t bvh, void* node_bytes, int32_t* object_i
 }
 
 }  // extern "C"
+
+// ---- RCCL glue ---------------------------------------------------------------------------------------
+// librccl is opened at run time: a host that renders on one GPU never loads it, and a process that already
+// holds a copy (PyTorch ships one) keeps using that copy.  Only the few entry points used here are bound;
+// their signatures are those of rccl.h (NCCL 2 API): ncclResult_t 0 = success, ncclFloat32 = 7, ncclSum = 0.
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, const void* /* ncclUniqueId by value, see init */, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string problem;
+};
+struct UniqueId { char bytes[PTK_COMM_ID_BYTES]; };  // ncclUniqueId: 128 opaque bytes, passed by value
+typedef int (*CommInitRankFn)(void**, int, UniqueId, int);
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);  // a copy already in the process
+        for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) { r.problem = std::string("librccl.so not found: ") + dlerror(); return; }
+        auto sym = [&](const char* name) { void* p = dlsym(r.lib, name); if (!p && r.problem.empty()) r.problem = std::string("librccl lacks ") + name; return p; };
+        r.GetUniqueId = (int (*)(void*))sym("ncclGetUniqueId");
+        r.CommInitRank = (int (*)(void**, int, const void*, int))sym("ncclCommInitRank");
+        r.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+        r.Reduce = (int (*)(const void*, void*, size_t, int, int, int, void*, hipStream_t))sym("ncclReduce");
+        r.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
+        r.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
+        r.GroupStart = (int (*)())sym("ncclGroupStart");
+        r.GroupEnd = (int (*)())sym("ncclGroupEnd");
+        r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    });
+    return r;
+}
+int rccl_fail(ptk_ctx* ctx, const char* what, int rc) {
+    Rccl& r = rccl();
+    return fail(ctx, PTK_E_HIP, "%s: %s", what, r.GetErrorString ? r.GetErrorString(rc) : "RCCL error");
+}
+#define RCCL_TRY(ctx, expr)                                  \
+    do {                                                     \
+        const int rc_ = (expr);                              \
+        if (rc_ != 0) return rccl_fail(ctx, #expr, rc_);     \
+    } while (0)
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;
+}  // namespace
+
+int ptk_comm_unique_id(void* id128) {
+    if (!id128) return PTK_E_INVALID;
+    Rccl& r = rccl();
+    if (!r.problem.empty()) return fail(nullptr, PTK_E_UNSUPPORTED, "%s", r.problem.c_str());
+    const int rc = r.GetUniqueId(id128);
+    if (rc != 0) return rccl_fail(nullptr, "ncclGetUniqueId", rc);
+    return PTK_OK;
+}
+
+int ptk_comm_init(ptk_ctx* ctx, int world, int rank, const void* id128) {
+    if (!ctx) return PTK_E_INVALID;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(ctx, PTK_E_INVALID, "bad communicator arguments (world %d, rank %d)", world, rank);
+    if (ctx->comm) return fail(ctx, PTK_E_STATE, "the context already belongs to a communicator");
+    Rccl& r = rccl();
+    if (!r.problem.empty()) return fail(ctx, PTK_E_UNSUPPORTED, "%s", r.problem.c_str());
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    UniqueId id;
+    memcpy(id.bytes, id128, sizeof id.bytes);
+    void* comm = nullptr;
+    RCCL_TRY(ctx, ((CommInitRankFn)(void*)r.CommInitRank)(&comm, world, id, rank));
+    ctx->comm = comm;
+    ctx->comm_world = world;
+    ctx->comm_rank = rank;
+    return PTK_OK;
+}
+
+int ptk_comm_destroy(ptk_ctx* ctx) {
+    if (!ctx) return PTK_E_INVALID;
+    if (!ctx->comm) return PTK_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    const int rc = rccl().CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_world = 0;
+    ctx->comm_rank = -1;
+    return rc == 0 ? PTK_OK : rccl_fail(ctx, "ncclCommDestroy", rc);
+}
+
+int ptk_image_reduce_mean(ptk_ctx* ctx, uint64_t image, int root) {
+    if (!ctx) return PTK_E_INVALID;
+    if (!ctx->comm) return fail(ctx, PTK_E_STATE, "ptk_comm_init has not been called");
+    Object* o = find(ctx, image, Kind::Image);
+    if (!o) return fail(ctx, PTK_E_INVALID, "unknown image handle");
+    if (root < 0 || root >= ctx->comm_world) return fail(ctx, PTK_E_INVALID, "root %d outside the communicator", root);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = flush_updates(ctx)) return rc;
+    Rccl& r = rccl();
+    // in place on root (its image receives the sum); the other ranks only send
+    RCCL_TRY(ctx, r.Reduce(o->dev, o->dev, o->nbytes / sizeof(float), kNcclFloat32, kNcclSum, root, ctx->comm, ctx->stream));
+    if (ctx->comm_rank == root && ctx->comm_world > 1)
+        HIP_TRY(ctx, ptk_launch_scale((float4*)o->dev, o->nbytes / 16, 1.0f / (float)ctx->comm_world, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTK_OK;
+}
+
+int ptk_image_gather_bands(ptk_ctx* ctx, uint64_t image, const int32_t* first_row, const int32_t* n_rows, int root) {
+    if (!ctx) return PTK_E_INVALID;
+    if (!ctx->comm) return fail(ctx, PTK_E_STATE, "ptk_comm_init has not been called");
+    Object* o = find(ctx, image, Kind::Image);
+    if (!o) return fail(ctx, PTK_E_INVALID, "unknown image handle");
+    if (!first_row || !n_rows || root < 0 || root >= ctx->comm_world) return fail(ctx, PTK_E_INVALID, "band tables and a root inside the communicator are required");
+    for (int k = 0; k < ctx->comm_world; k++)
+        if (first_row[k] < 0 || n_rows[k] < 0 || (long long)first_row[k] + n_rows[k] > o->height)
+            return fail(ctx, PTK_E_INVALID, "band of rank %d (rows %d..%d) leaves the image (%d rows)", k, first_row[k], first_row[k] + n_rows[k], o->height);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = flush_updates(ctx)) return rc;
+    Rccl& r = rccl();
+    const size_t row_floats = (size_t)o->width * 4;
+    float* base = (float*)o->dev;
+    RCCL_TRY(ctx, r.GroupStart());
+    if (ctx->comm_rank == root) {
+        for (int k = 0; k < ctx->comm_world; k++)
+            if (k != root && n_rows[k] > 0)
+                RCCL_TRY(ctx, r.Recv(base + (size_t)first_row[k] * row_floats, (size_t)n_rows[k] * row_floats, kNcclFloat32, k, ctx->comm, ctx->stream));
+    } else if (n_rows[ctx->comm_rank] > 0) {
+        RCCL_TRY(ctx, r.Send(base + (size_t)first_row[ctx->comm_rank] * row_floats, (size_t)n_rows[ctx->comm_rank] * row_floats, kNcclFloat32, root,
+                             ctx->comm, ctx->stream));
+    }
+    RCCL_TRY(ctx, r.GroupEnd());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTK_OK;
+}

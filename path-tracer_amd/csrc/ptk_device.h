@@ -132,6 +132,7 @@ extern "C" hipError_t ptk_persistent_scratch_init(int device);
 extern "C" void* ptk_persistent_scratch(int device);
 // Display conversion (ptk_display.hip): rgba32f image -> RGBA8, n_pixels * 4 bytes at out_rgba8 (device, 16-byte aligned).
 extern "C" hipError_t ptk_launch_display(const float4* image, void* out_rgba8, size_t n_pixels, int transfer, hipStream_t stream);
+extern "C" hipError_t ptk_launch_scale(float4* image, size_t n_pixels, float s, hipStream_t stream);
 
 // Mesh ingestion (ptk_mesh.hip): one Godot ArrayMesh surface to triangle records; all pointers are device pointers.
 struct PtkMeshJob {

@@ -60,3 +60,16 @@ extern "C" hipError_t ptk_launch_display(const float4* image, void* out_rgba8, s
                        n_pixels, (uint32_t*)out_rgba8, transfer);
     return hipGetLastError();
 }
+
+// image *= s (the 1/world of a reduced sum of per-GPU means)
+__global__ void ptk_scale_kernel(float4* p, size_t n, float s) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 v = p[i];
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    p[i] = v;
+}
+extern "C" hipError_t ptk_launch_scale(float4* image, size_t n_pixels, float s, hipStream_t stream) {
+    hipLaunchKernelGGL(ptk_scale_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream, image, n_pixels, s);
+    return hipGetLastError();
+}

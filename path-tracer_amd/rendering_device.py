@@ -28,7 +28,8 @@ EXPORTS = [
     "ptk_create", "ptk_destroy", "ptk_last_error", "ptk_configure", "ptk_buffer_create", "ptk_buffer_update",
     "ptk_buffer_read", "ptk_image_create", "ptk_image_read", "ptk_image_update", "ptk_texture_create",
     "ptk_dispatch", "ptk_sync", "ptk_free", "ptk_bvh_build", "ptk_bvh_sizes", "ptk_bvh_read",
-    "ptk_trace_enable", "ptk_trace_read", "ptk_last_dispatch_ms", "ptk_dispatch_history_ms", "ptk_image_copy_device",
+    "ptk_trace_enable", "ptk_trace_read", "ptk_last_dispatch_ms", "ptk_dispatch_history_ms", "ptk_image_copy_device", "ptk_comm_unique_id", "ptk_comm_init", "ptk_image_reduce_mean",
+    "ptk_image_gather_bands", "ptk_comm_destroy",
     "ptk_set_renderer", "ptk_dispatch_traverse_ms", "ptk_update_stats", "ptk_dispatch_noalloc",
     "ptk_image_read_display", "ptk_mesh_to_triangles", "ptk_set_option",
     "ptk_bvh_bind", "ptk_bvh_refit",
@@ -125,6 +126,16 @@ def load_library() -> C.CDLL:
     lib.ptk_dispatch_history_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     lib.ptk_image_copy_device.restype = C.c_int
     lib.ptk_image_copy_device.argtypes = [vp, u64, vp, C.c_size_t, C.c_int]
+    lib.ptk_comm_unique_id.restype = C.c_int
+    lib.ptk_comm_unique_id.argtypes = [vp]
+    lib.ptk_comm_init.restype = C.c_int
+    lib.ptk_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.ptk_image_reduce_mean.restype = C.c_int
+    lib.ptk_image_reduce_mean.argtypes = [vp, u64, C.c_int]
+    lib.ptk_image_gather_bands.restype = C.c_int
+    lib.ptk_image_gather_bands.argtypes = [vp, u64, vp, vp, C.c_int]
+    lib.ptk_comm_destroy.restype = C.c_int
+    lib.ptk_comm_destroy.argtypes = [vp]
     lib.ptk_update_stats.restype = C.c_int
     lib.ptk_update_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     lib.ptk_set_renderer.restype = C.c_int
@@ -349,6 +360,33 @@ class PtkRenderingDevice:
         a, b = C.c_longlong(0), C.c_longlong(0)
         self._check(self.lib.ptk_update_stats(self.ctx, C.byref(a), C.byref(b)), "ptk_update_stats")
         return int(a.value), int(b.value)
+
+    # ---- RCCL from the C ABI (hosts without torch.distributed) ----
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId: made on rank 0, handed to every rank's comm_init."""
+        buf = (C.c_ubyte * 128)()
+        rc = load_library().ptk_comm_unique_id(buf)
+        if rc != 0:
+            raise PtkError(f"ptk_comm_unique_id failed ({rc}): {load_library().ptk_last_error(None).decode()}")
+        return bytes(buf)
+
+    def comm_init(self, world: int, rank: int, unique_id: bytes):
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.ptk_comm_init(self.ctx, int(world), int(rank), buf), "ptk_comm_init")
+
+    def image_reduce_mean(self, image: int, root: int = 0):
+        """Sample batches: root's image becomes the mean over the ranks' images."""
+        self._check(self.lib.ptk_image_reduce_mean(self.ctx, image, int(root)), "ptk_image_reduce_mean")
+
+    def image_gather_bands(self, image: int, first_row, n_rows, root: int = 0):
+        """Tile rows: root's image receives every rank's band of rows."""
+        a = np.ascontiguousarray(first_row, dtype=np.int32)
+        b = np.ascontiguousarray(n_rows, dtype=np.int32)
+        self._check(self.lib.ptk_image_gather_bands(self.ctx, image, a.ctypes.data, b.ctypes.data, int(root)), "ptk_image_gather_bands")
+
+    def comm_destroy(self):
+        self._check(self.lib.ptk_comm_destroy(self.ctx), "ptk_comm_destroy")
 
     def set_option(self, option: int, value: int):
         """PTK_OPT_* switches (1 = PTK_OPT_TRIANGLE_UVS: interpolate the corner UVs bound at (4,1))."""

@@ -81,3 +81,45 @@ def test_display_conversion(pta, transfer):
         dev.free_rid(image)
     finally:
         dev.close()
+
+
+def test_rccl_entry_points_with_one_rank(pta, golden_dir):
+    """ptk_comm_* / ptk_image_reduce_mean / ptk_image_gather_bands with a communicator of one rank (all a one-GPU box
+    can hold: RCCL refuses two ranks on one device): librccl is found and bound at run time, the mean over one
+    rank and the gather of one band leave the image bit for bit as it was, and misuse fails with a message."""
+    import oracle_binding as ob
+    wd = pta.work_dispatcher
+    scene = pta.scenes.load_fixture_scene("sphere_scene1", golden_dir)
+    packed = wd.pack_scene(scene, ob.OracleBvhBuilder(), 8)
+    w, h = 128, 72
+    dev = pta.PtkRenderingDevice(0)
+    try:
+        disp = wd.PTWorkDispatcher(dev)
+        disp.create_buffers(w, h, packed=packed)
+        disp.load_shader()
+        win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=4)
+        win.frame = 1
+        disp.create_compute_list(win, scene.camera, wd.sample_time(0), sync=True)
+        before = dev.texture_get_data(disp.image_buffer).copy()
+        with pytest.raises(pta.rendering_device.PtkError, match="ptk_comm_init has not been called"):
+            dev.image_reduce_mean(disp.image_buffer, 0)
+        uid = pta.PtkRenderingDevice.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        with pytest.raises(pta.rendering_device.PtkError):
+            dev.comm_init(1, 3, uid)  # rank outside the world
+        dev.comm_init(1, 0, uid)
+        with pytest.raises(pta.rendering_device.PtkError, match="already belongs"):
+            dev.comm_init(1, 0, uid)
+        dev.image_reduce_mean(disp.image_buffer, 0)
+        assert np.array_equal(dev.texture_get_data(disp.image_buffer).view(np.uint32), before.view(np.uint32))
+        dev.image_gather_bands(disp.image_buffer, [0], [h], 0)
+        assert np.array_equal(dev.texture_get_data(disp.image_buffer).view(np.uint32), before.view(np.uint32))
+        with pytest.raises(pta.rendering_device.PtkError, match="leaves the image"):
+            dev.image_gather_bands(disp.image_buffer, [8], [h], 0)
+        with pytest.raises(pta.rendering_device.PtkError, match="outside the communicator"):
+            dev.image_reduce_mean(disp.image_buffer, 1)
+        dev.comm_destroy()
+        dev.comm_destroy()  # idempotent
+        disp.free_rids()
+    finally:
+        dev.close()
