@@ -1,0 +1,27 @@
+"""Per-bounce durations of the wavefront pipeline's traversal launches on the bench scene, beside the whole
+dispatch's kernel time (development aid: where the tail of late bounces sits)."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pta = importlib.import_module("path-tracer_amd")
+wd = pta.work_dispatcher
+scene = pta.scenes.atrium_scene(262144, seed=7)
+rd = pta.PtkRenderingDevice(0)
+disp = wd.PTWorkDispatcher(rd)
+disp.set_scene(scene)
+disp.create_buffers(1920, 1080, order=8)
+disp.load_shader()
+rd.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
+win = wd.PTRenderWindow(render_width=1920, render_height=1080, max_ray_depth=8, max_refraction_bounces=4)
+acc = None
+n = 10
+for k in range(n + 2):
+    win.frame = k
+    disp.create_compute_list(win, scene.camera, wd.sample_time(k), sync=True)
+    if k >= 2:
+        t = np.array(rd.dispatch_traverse_ms(0))
+        acc = t if acc is None else acc + t
+total = rd.dispatch_history_ms(n)
+print("traverse launches, mean ms per bounce:", " ".join("%.3f" % x for x in acc / n))
+print("sum %.3f ms of %.3f ms per dispatch" % (acc.sum() / n, float(np.mean(total))))
