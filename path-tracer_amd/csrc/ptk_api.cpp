@@ -1349,6 +1349,16 @@ int ptk_dev_wf_stats(ptk_ctx* ctx, unsigned long long* out, int n) {
 }
 #endif
 
+#ifdef PTK_WF_ENDS
+extern "C" hipError_t ptk_wf_ends_fetch(unsigned long long* out, size_t n, hipStream_t stream);
+int ptk_dev_wf_ends(ptk_ctx* ctx, unsigned long long* out, size_t n) {
+    if (!ctx || !out) return PTK_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, ptk_wf_ends_fetch(out, n, ctx->stream));
+    return PTK_OK;
+}
+#endif
+
 int ptk_update_stats(ptk_ctx* ctx, long long* full_validations, long long* patched_updates) {
     if (!ctx || !full_validations || !patched_updates) return PTK_E_INVALID;
     *full_validations = ctx->full_validations;

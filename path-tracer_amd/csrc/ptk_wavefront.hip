@@ -95,6 +95,18 @@ extern "C" hipError_t ptk_wf_stats_fetch(unsigned long long* out, int n, hipStre
 }
 #endif
 
+#ifdef PTK_WF_ENDS
+// Measurement build: when every wave of a traversal launch started and ended (100 MHz wall clock), per bounce.
+#define PTK_WF_ENDS_ITERS 16
+#define PTK_WF_ENDS_WAVES 8192
+__device__ unsigned long long g_wf_ends[PTK_WF_ENDS_ITERS * PTK_WF_ENDS_WAVES * 2];
+extern "C" hipError_t ptk_wf_ends_fetch(unsigned long long* out, size_t n, hipStream_t stream) {
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wf_ends), sizeof(unsigned long long) * n);
+}
+#endif
+
 __global__ __launch_bounds__(64) void ptk_wf_generate(const PtkParams P) {
     const PtkWavefront& W = P.wf;
     const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
@@ -121,6 +133,10 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
     extern __shared__ __attribute__((aligned(16))) int lds_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const PtkWavefront& W = P.wf;
+#ifdef PTK_WF_ENDS
+    const size_t ends_at = ((size_t)iter * PTK_WF_ENDS_WAVES + blockIdx.x * PTK_WF_WG_WAVES + wave) * 2;
+    if (lane == 0 && iter < PTK_WF_ENDS_ITERS) g_wf_ends[ends_at] = wall_clock64();
+#endif
     {
         float4* top = (float4*)lds_all;
         for (uint32_t i = threadIdx.x; i < W.n_top * 16u; i += PTK_WF_WG_WAVES * 64)
@@ -213,6 +229,9 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
         }
         if (pop) trav_pop(S, T);
     }
+#ifdef PTK_WF_ENDS
+    if (lane == 0 && iter < PTK_WF_ENDS_ITERS) g_wf_ends[ends_at + 1] = wall_clock64();
+#endif
 }
 
 // The bounce-loop body after the closest-hit search (:1583-1621) for every ray of bounce `iter`, and
