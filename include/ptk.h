@@ -234,7 +234,7 @@ int ptk_dispatch_history_ms(ptk_ctx* ctx, float* ms, int n);
  * tile (ray_tracer.comp:1553-1635 as written); WAVEFRONT, a pipeline with one traversal launch and one
  * shading launch per bounce over ray queues in device memory; PERSISTENT, one kernel of persistent
  * waves whose lanes take a new pixel as soon as their path ends.  WAVEFRONT and PERSISTENT cover plain
- * render mode with the BVH flag set, no tracing and no early-t variant (WAVEFRONT: at most 32 bounces).
+ * render mode with the BVH flag set, no tracing and no early-t variant (WAVEFRONT: at most 64 bounces).
  * Where several apply, AUTO times each on the first dispatches of a workload (scene contents, group
  * counts, depth limits) and keeps the fastest: the pipeline wins on heavy scenes, the persistent kernel
  * on light scenes whose paths differ in length, the tile kernel on light scenes whose paths do not.

@@ -133,6 +133,9 @@ struct ptk_ctx {
     size_t wf_spill_ints = 0;
     int n_cus = 0;
     int lds_window = 32;           // traversal stack entries per lane kept in LDS (PTK_LDS_WINDOW, read once at create)
+    bool wf_carry = true;          // the pipeline parks unfinished searches for the next launch (PTK_WF_CARRY=0 turns it off; read once at create)
+    void* d_wf_carry = nullptr;
+    size_t wf_carry_bytes = 0;
     int waves_per_cu_cap = 0;      // > 0: upper bound on persistent waves per CU (PTK_WF_WAVES_PER_CU, read once at create)
     int wf_wgs_per_cu = 0, pp_waves_per_cu = 0;  // occupancy of the two persistent kernels for the bound scene's LDS need
     uint32_t n_top = 0;            // blocks [0, n_top): top of the tree, breadth-first, LDS-resident in the traversal kernel
@@ -214,6 +217,7 @@ ptk_ctx* ptk_create(int device_ordinal) {
     if (ok) ctx->n_cus = prop.multiProcessorCount;
     // development knobs are read here once: a variable that appears in the host's environment later changes nothing
     if (const char* w = getenv("PTK_LDS_WINDOW")) ctx->lds_window = std::max(8, std::min(64, atoi(w)));
+    if (const char* w = getenv("PTK_WF_CARRY")) ctx->wf_carry = atoi(w) != 0;
     if (const char* c = getenv("PTK_WF_WAVES_PER_CU")) ctx->waves_per_cu_cap = std::max(1, atoi(c));
     if (!ok) {
         fail(nullptr, PTK_E_HIP, "stream/event creation failed");
@@ -247,6 +251,7 @@ void ptk_destroy(ptk_ctx* ctx) {
     if (ctx->d_leaf_records) (void)hipFree(ctx->d_leaf_records);
     if (ctx->d_wf) (void)hipFree(ctx->d_wf);
     if (ctx->d_wf_spill) (void)hipFree(ctx->d_wf_spill);
+    if (ctx->d_wf_carry) (void)hipFree(ctx->d_wf_carry);
     if (ctx->d_pixel_counter) (void)hipFree(ctx->d_pixel_counter);
     if (ctx->d_display) (void)hipFree(ctx->d_display);
     for (int k = 0; k < 2; k++) {
@@ -1243,6 +1248,7 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         const size_t cap = ctx->wf_slots;
         P.wf.counts = (uint32_t*)base;                       // counts then heads, zeroed per dispatch
         P.wf.heads = P.wf.counts + (PTK_WF_MAX_ITER + 1);
+        P.wf.n_resume = P.wf.heads + (PTK_WF_MAX_ITER + 1);
         base += 1024;
         P.wf.rays[0] = (float4*)base; base += cap * 32;
         P.wf.rays[1] = (float4*)base; base += cap * 32;
@@ -1273,13 +1279,31 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         }
         P.spill = ctx->d_wf_spill;
     }
+    // carry-over of unfinished searches between launches: room for every lane in flight, for both queue parities
+    int n_launches = n_iter;
+    P.wf.carry[0] = P.wf.carry[1] = nullptr;
+    P.wf.carry_cap = 0;
+    if (ctx->wf_carry && n_iter > 1 && n_iter + PTK_WF_MAX_LAG <= PTK_WF_MAX_ITER) {
+        const size_t cap = n_waves * 64;
+        const size_t bytes = (size_t)(PTK_WF_CARRY_PLANES + P.lds_cap) * cap * 4;
+        if (2 * bytes > ctx->wf_carry_bytes) {
+            if (ctx->d_wf_carry) { (void)hipFree(ctx->d_wf_carry); ctx->d_wf_carry = nullptr; }
+            ctx->wf_carry_bytes = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_wf_carry, 2 * bytes));
+            ctx->wf_carry_bytes = 2 * bytes;
+        }
+        P.wf.carry[0] = (uint32_t*)ctx->d_wf_carry;
+        P.wf.carry[1] = (uint32_t*)((uint8_t*)ctx->d_wf_carry + bytes);
+        P.wf.carry_cap = (uint32_t)cap;
+        n_launches = n_iter + PTK_WF_MAX_LAG;  // a parked path runs at most this many launches behind its bounce number
+    }
     if (!ctx->wf_ev[slot]) {
         ctx->wf_ev[slot] = new hipEvent_t[2 * PTK_WF_MAX_ITER];
         for (int k = 0; k < 2 * PTK_WF_MAX_ITER; k++) HIP_TRY(ctx, hipEventCreate(&ctx->wf_ev[slot][k]));
     }
-    ctx->wf_iters[slot] = n_iter;
+    ctx->wf_iters[slot] = n_launches;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
-    HIP_TRY(ctx, ptk_launch_wavefront(&P, groups_x, groups_y, n_iter, wf_lds, n_wgs, ctx->wf_ev[slot], ctx->stream));
+    HIP_TRY(ctx, ptk_launch_wavefront(&P, groups_x, groups_y, n_launches, wf_lds, n_wgs, ctx->wf_ev[slot], ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
     ctx->dispatch_count++;
     return PTK_OK;

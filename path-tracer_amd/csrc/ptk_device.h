@@ -39,7 +39,9 @@ struct PtkTexDesc {
 // A queue entry is two float4: {origin.xyz, bits(pixel slot)}, {direction.xyz, 0}, plus the path state
 // in a parallel array that only the shading kernel touches; the hit record of
 // entry i is hits[i] = {hit, object_id, transform_index, bits(t)} and hit_uv[i].
-#define PTK_WF_MAX_ITER 32
+#define PTK_WF_MAX_ITER 64
+#define PTK_WF_MAX_LAG 2       // launches a path may fall behind its bounce number by being carried over (see PtkWavefront::carry)
+#define PTK_WF_CARRY_PLANES 25 // words of search state carried besides the stack rows
 // The top of many trees is a chain every ray walks in the same way: a root with one child, a mesh socket, a
 // mesh root with one child (scene root -> PTMesh socket -> mesh tree is the plugin's usual layout).  Those
 // steps need no per-lane node fetch: the host lists them here (they travel as kernel arguments) and every
@@ -55,8 +57,17 @@ struct PtkWavefront {
     float4* rays[2];
     int4* hits;
     float2* hit_uv;
-    uint32_t* counts;  // counts[i] = rays queued for bounce i          (PTK_WF_MAX_ITER + 1 words)
-    uint32_t* heads;   // heads[i]  = rays of bounce i handed to waves  (PTK_WF_MAX_ITER + 1 words)
+    uint32_t* counts;  // counts[i] = rays the shading of launch i-1 queued for launch i (PTK_WF_MAX_ITER + 1 words)
+    uint32_t* heads;   // heads[i]  = rays of launch i handed to waves               (PTK_WF_MAX_ITER + 1 words)
+    // Carry-over: when the queue of launch i runs dry, a wave does not sit out the searches it still has in
+    // flight but parks them -- ray, path state, search state, stack -- at the front of launch i+1's queue
+    // (entries [0, n_resume[i+1])), where full waves pick them up again.  A launch then ends when its queue
+    // is empty instead of when its slowest ray is done; a parked path is one launch behind its bounce number
+    // (its own number travels in the ray's d.w), at most PTK_WF_MAX_LAG launches, which the host appends.
+    uint32_t* n_resume;  // (PTK_WF_MAX_ITER + 2 words)
+    uint32_t* carry[2];  // parked search state for the queue of that parity: [plane][carry_cap], PTK_WF_CARRY_PLANES planes
+                         // then one per stack row of the LDS window; null = no carry-over
+    uint32_t carry_cap;
     float4* state[2];  // path state travelling with the queue entry, two float4 per entry:
                        // {throughput rgba}, {seed, current_IOR, bits(inside_of_count),
                        //  bits(refraction_bounces | inside-arrays-stored << 30)}

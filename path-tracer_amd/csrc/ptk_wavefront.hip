@@ -110,7 +110,7 @@ extern "C" hipError_t ptk_wf_ends_fetch(unsigned long long* out, size_t n, hipSt
 __global__ __launch_bounds__(64) void ptk_wf_generate(const PtkParams P) {
     const PtkWavefront& W = P.wf;
     const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
-    if (slot == 0) W.counts[0] = W.n_slots;
+    if (slot == 0) W.counts[0] = W.n_slots;  // (n_resume[0] stays 0)
     int gx, gy;
     slot_to_pixel(P, slot, gx, gy);
     const Primary pr = primary_ray(P.push, gx, gy);
@@ -118,6 +118,47 @@ __global__ __launch_bounds__(64) void ptk_wf_generate(const PtkParams P) {
     W.rays[0][(size_t)slot * 2 + 1] = make_float4(pr.ray.d.x, pr.ray.d.y, pr.ray.d.z, 0.0f);
     W.state[0][(size_t)slot * 2] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     W.state[0][(size_t)slot * 2 + 1] = make_float4(pr.seed, 1.0f, bitsf(0u), bitsf(0u));
+}
+
+// Parking a search that is under way (see PtkWavefront::carry) and taking it up again.  Everything a Trav holds
+// goes along except inv, which is 1 / d again; the stack rows below sp (all inside the LDS window, the caller
+// checks) follow the PTK_WF_CARRY_PLANES state words.  Planes are [word][entry]: the lanes of a wave park to and
+// resume from consecutive entries.
+PTK_DEV void wf_park(const PtkWavefront& W, const Stack& S, const Trav& T, int iter, uint32_t ray_idx, uint32_t at) {
+    const int from = iter & 1, to = (iter + 1) & 1;
+    // the queue entry moves to the front of the next queue as it is: world ray, pixel slot, bounce number, path state
+    W.rays[to][(size_t)at * 2] = W.rays[from][(size_t)ray_idx * 2];
+    W.rays[to][(size_t)at * 2 + 1] = W.rays[from][(size_t)ray_idx * 2 + 1];
+    W.state[to][(size_t)at * 2] = W.state[from][(size_t)ray_idx * 2];
+    W.state[to][(size_t)at * 2 + 1] = W.state[from][(size_t)ray_idx * 2 + 1];
+    W.hits[ray_idx] = make_int4(-2, 0, 0, 0);  // this launch's shading passes the entry over
+    uint32_t* c = W.carry[to] + at;
+    const size_t cap = W.carry_cap;
+    const uint32_t w[PTK_WF_CARRY_PLANES] = {
+        fbits(T.o.x), fbits(T.o.y), fbits(T.o.z), fbits(T.d.x), fbits(T.d.y), fbits(T.d.z), fbits(T.start), fbits(T.end),
+        (uint32_t)T.h.hit, (uint32_t)T.h.object_id, (uint32_t)T.h.transform_index, fbits(T.h.u), fbits(T.h.v),
+        T.cur, (uint32_t)T.sp, (uint32_t)T.sub_base, (uint32_t)T.cur_xf,
+        fbits(T.w_o.x), fbits(T.w_o.y), fbits(T.w_o.z), fbits(T.w_d.x), fbits(T.w_d.y), fbits(T.w_d.z), fbits(T.w_start), fbits(T.dir_len)};
+#pragma unroll
+    for (int k = 0; k < PTK_WF_CARRY_PLANES; k++) c[(size_t)k * cap] = w[k];
+    for (int r = 0; r < T.sp; r++) c[(size_t)(PTK_WF_CARRY_PLANES + r) * cap] = (uint32_t)S.lds[r * 64 + S.lane];
+}
+PTK_DEV void wf_unpark(const PtkWavefront& W, const Stack& S, Trav& T, int parity, uint32_t at) {
+    const uint32_t* c = W.carry[parity] + at;
+    const size_t cap = W.carry_cap;
+    uint32_t w[PTK_WF_CARRY_PLANES];
+#pragma unroll
+    for (int k = 0; k < PTK_WF_CARRY_PLANES; k++) w[k] = c[(size_t)k * cap];
+    T.o = mk3(bitsf(w[0]), bitsf(w[1]), bitsf(w[2]));
+    T.d = mk3(bitsf(w[3]), bitsf(w[4]), bitsf(w[5]));
+    T.start = bitsf(w[6]); T.end = bitsf(w[7]);
+    T.inv = mk3(1.0f / T.d.x, 1.0f / T.d.y, 1.0f / T.d.z);
+    T.h.hit = (int)w[8]; T.h.object_id = (int)w[9]; T.h.transform_index = (int)w[10]; T.h.u = bitsf(w[11]); T.h.v = bitsf(w[12]);
+    T.cur = w[13]; T.sp = (int)w[14]; T.sub_base = (int)w[15]; T.cur_xf = (int)w[16];
+    T.w_o = mk3(bitsf(w[17]), bitsf(w[18]), bitsf(w[19]));
+    T.w_d = mk3(bitsf(w[20]), bitsf(w[21]), bitsf(w[22]));
+    T.w_start = bitsf(w[23]); T.dir_len = bitsf(w[24]);
+    for (int r = 0; r < T.sp; r++) S.lds[r * 64 + S.lane] = (int)c[(size_t)(PTK_WF_CARRY_PLANES + r) * cap];
 }
 
 // Closest hit of every ray of bounce `iter`.  Per lane this is the block traversal of
@@ -149,13 +190,16 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
     S.lane = lane; S.lds_cap = P.lds_cap; S.spill_stride = P.spill_stride;
     S.spill = P.spill ? P.spill + ((size_t)blockIdx.x * PTK_WF_WG_WAVES + wave) * 64 + lane : nullptr;
 
-    const uint32_t count = __builtin_amdgcn_readfirstlane(W.counts[iter]);
+    const uint32_t n_res = __builtin_amdgcn_readfirstlane(W.n_resume[iter]);  // parked searches at the queue's front
+    const uint32_t count = n_res + __builtin_amdgcn_readfirstlane(W.counts[iter]);
     const float4* __restrict__ rq = W.rays[iter & 1];
+    const bool carry_on = W.carry[0] != nullptr;
     uint32_t c_next = 0, c_end = 0;  // this wave's claimed queue range
     bool exhausted = count == 0;
 
     bool have = false;  // the lane holds a ray
     uint32_t ray_idx = 0;
+    int ray_bounce = 0;  // the bounce number of the lane's path (<= iter)
     Trav T;
     T.o = mk3(0, 0, 0); T.d = mk3(0, 0, 1); T.start = 0.0f; T.end = 0.0f;
     T.inv = mk3(0, 0, 0);
@@ -201,11 +245,31 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
                     wr.d = mk3(b.x, b.y, b.z);
                     wr.start = 0.0f;
                     wr.end = PT_INF;
-                    trav_begin(P, T, wr);
+                    ray_bounce = (int)fbits(b.w);
+                    if (ray_idx < n_res) wf_unpark(W, S, T, iter & 1, ray_idx);
+                    else trav_begin(P, T, wr);
                     have = true;
                 }
                 const uint32_t wanted = (uint32_t)__popcll(need);
                 c_next += wanted < avail ? wanted : avail;
+            }
+            if (exhausted && carry_on) {
+                // the queue is dry: park what is still searching, unless the path is too far behind already or
+                // part of its stack lives in the spill column
+                const bool park = have && T.cur != ENTRY_NONE && T.sp <= S.lds_cap && iter - ray_bounce < PTK_WF_MAX_LAG;
+                const unsigned long long pm = __ballot(park);
+                if (pm != 0ull) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(W.n_resume + iter + 1, (uint32_t)__popcll(pm));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (park) {
+                        const uint32_t at = base + (uint32_t)lane_rank_in(pm);
+                        if (at < W.carry_cap) {
+                            wf_park(W, S, T, iter, ray_idx, at);
+                            have = false;
+                        }
+                    }
+                }
             }
             if (exhausted && __ballot(have) == 0ull) break;
             continue;
@@ -240,7 +304,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void ptk_wf_shade(const PtkParams P, i
     __shared__ uint32_t s_wave_total[SHADE_BLOCK / 64];
     __shared__ uint32_t s_base;
     const PtkWavefront& W = P.wf;
-    const uint32_t count = W.counts[iter];
+    const uint32_t count = W.n_resume[iter] + W.counts[iter];
     if (blockIdx.x * (uint32_t)SHADE_BLOCK >= count) return;  // the whole block is past the queue's end
     const uint32_t idx = blockIdx.x * (uint32_t)SHADE_BLOCK + threadIdx.x;
     const bool track_inside = P.refraction_mode == 2;
@@ -252,9 +316,12 @@ __global__ __launch_bounds__(SHADE_BLOCK) void ptk_wf_shade(const PtkParams P, i
     float4 new_color = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     bool inside_stored = false;
     bool going = false;
-    if (idx < count) {
+    int bounce = 0;  // the path's own bounce number (a parked path is behind the launch number)
+    // (hit == -2: the search was parked for the next launch, nothing to shade yet)
+    if (idx < count && W.hits[idx].x != -2) {
         const float4 qa = W.rays[iter & 1][(size_t)idx * 2], qb = W.rays[iter & 1][(size_t)idx * 2 + 1];
         slot = fbits(qa.w);
+        bounce = (int)fbits(qb.w);
         const int4 hr = W.hits[idx];
         const float2 uv = W.hit_uv[idx];
         nr.o = mk3(qa.x, qa.y, qa.z);
@@ -303,7 +370,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void ptk_wf_shade(const PtkParams P, i
                     new_color.z *= s.albedo.z * tex_col.z;
                     new_color.w *= 1.0f * tex_col.w;
                 }
-                done = !(iter + 1 < P.push.max_default_depth + L.refraction_bounces);
+                done = !(bounce + 1 < P.push.max_default_depth + L.refraction_bounces);
             }
         }
 
@@ -332,7 +399,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void ptk_wf_shade(const PtkParams P, i
     }
     __syncthreads();
     if (!going) return;
-    uint32_t pos = s_base + (uint32_t)lane_rank_in(mask);
+    uint32_t pos = W.n_resume[iter + 1] + s_base + (uint32_t)lane_rank_in(mask);  // behind what the traversal parked there
     for (int w = 0; w < wave; w++) pos += s_wave_total[w];
 
     bool inside_default = true;
@@ -348,7 +415,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void ptk_wf_shade(const PtkParams P, i
     }
     float4* out = W.rays[(iter + 1) & 1];
     out[(size_t)pos * 2] = make_float4(nr.o.x, nr.o.y, nr.o.z, bitsf(slot));
-    out[(size_t)pos * 2 + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, 0.0f);
+    out[(size_t)pos * 2 + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, bitsf((uint32_t)(bounce + 1)));
     float4* sout = W.state[(iter + 1) & 1];
     sout[(size_t)pos * 2] = new_color;
     sout[(size_t)pos * 2 + 1] = make_float4(L.seed, L.current_IOR, bitsf((uint32_t)L.inside_of_count),

@@ -95,7 +95,7 @@ def test_empty_scene_is_all_sky(pta, rd, rd_wf, golden_dir):
 
 
 def test_wavefront_hands_over_outside_its_range(pta, rd, golden_dir):
-    """More than 32 bounces, or depth 0: AUTO does not use the pipeline (same image as the oracle), and a
+    """More than 64 bounces, or depth 0: AUTO does not use the pipeline (same image as the oracle), and a
     context pinned to the wavefront pipeline reports the dispatch as unsupported.  The persistent kernel has
     no bound on the bounce count; depth 0 it refuses too."""
     wd = pta.work_dispatcher
@@ -107,7 +107,7 @@ def test_wavefront_hands_over_outside_its_range(pta, rd, golden_dir):
         d = wd.PTWorkDispatcher(dev)
         d.create_buffers(w, h, packed=packed)
         d.load_shader()
-        for depth, bounces in [(40, 4), (0, 4), (8, 4)]:
+        for depth, bounces in [(70, 4), (0, 4), (8, 4)]:
             dev.texture_update(d.image_buffer, np.zeros((h, w, 4), np.float32))
             cpu = np.zeros((h, w, 4), np.float32)
             win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=depth, max_refraction_bounces=bounces)
@@ -130,6 +130,15 @@ def test_wavefront_hands_over_outside_its_range(pta, rd, golden_dir):
                     dev.texture_update(d.image_buffer, np.zeros((h, w, 4), np.float32))
                     d.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
                     _compare_image(f"depth{depth} persistent", dev.texture_get_data(d.image_buffer), cpu)
+        # 40 bounces are inside the pipeline's range: pinned to it, the image is the oracle's
+        dev.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
+        dev.texture_update(d.image_buffer, np.zeros((h, w, 4), np.float32))
+        cpu = np.zeros((h, w, 4), np.float32)
+        win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=40, max_refraction_bounces=4)
+        ob.render(packed, wd.push_constant_bytes(scene.camera, win, wd.sample_time(1)), cpu, w // 8, h // 8)
+        d.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
+        assert len(dev.dispatch_traverse_ms(0)) > 40
+        _compare_image("depth40 pipeline", dev.texture_get_data(d.image_buffer), cpu)
         d.free_rids()
     finally:
         dev.close()
