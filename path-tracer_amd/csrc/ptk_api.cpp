@@ -134,6 +134,7 @@ struct ptk_ctx {
     int n_cus = 0;
     int lds_window = 32;           // traversal stack entries per lane kept in LDS (PTK_LDS_WINDOW, read once at create)
     bool wf_carry = true;          // the pipeline parks unfinished searches for the next launch (PTK_WF_CARRY=0 turns it off; read once at create)
+    int wf_max_lag = 2, wf_park_below = 32;  // (PTK_WF_MAX_LAG, PTK_WF_PARK_BELOW: tuning, read once at create)
     void* d_wf_carry = nullptr;
     size_t wf_carry_bytes = 0;
     int waves_per_cu_cap = 0;      // > 0: upper bound on persistent waves per CU (PTK_WF_WAVES_PER_CU, read once at create)
@@ -218,6 +219,8 @@ ptk_ctx* ptk_create(int device_ordinal) {
     // development knobs are read here once: a variable that appears in the host's environment later changes nothing
     if (const char* w = getenv("PTK_LDS_WINDOW")) ctx->lds_window = std::max(8, std::min(64, atoi(w)));
     if (const char* w = getenv("PTK_WF_CARRY")) ctx->wf_carry = atoi(w) != 0;
+    if (const char* w = getenv("PTK_WF_MAX_LAG")) ctx->wf_max_lag = std::max(1, std::min(PTK_WF_MAX_LAG, atoi(w)));
+    if (const char* w = getenv("PTK_WF_PARK_BELOW")) ctx->wf_park_below = std::max(1, std::min(64, atoi(w)));
     if (const char* c = getenv("PTK_WF_WAVES_PER_CU")) ctx->waves_per_cu_cap = std::max(1, atoi(c));
     if (!ok) {
         fail(nullptr, PTK_E_HIP, "stream/event creation failed");
@@ -1283,7 +1286,9 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     int n_launches = n_iter;
     P.wf.carry[0] = P.wf.carry[1] = nullptr;
     P.wf.carry_cap = 0;
-    if (ctx->wf_carry && n_iter > 1 && n_iter + PTK_WF_MAX_LAG <= PTK_WF_MAX_ITER) {
+    P.wf.max_lag = ctx->wf_max_lag;
+    P.wf.park_below = ctx->wf_park_below;
+    if (ctx->wf_carry && n_iter > 1 && n_iter + ctx->wf_max_lag <= PTK_WF_MAX_ITER) {
         const size_t cap = n_waves * 64;
         const size_t bytes = (size_t)(PTK_WF_CARRY_PLANES + P.lds_cap) * cap * 4;
         if (2 * bytes > ctx->wf_carry_bytes) {
@@ -1295,7 +1300,7 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         P.wf.carry[0] = (uint32_t*)ctx->d_wf_carry;
         P.wf.carry[1] = (uint32_t*)((uint8_t*)ctx->d_wf_carry + bytes);
         P.wf.carry_cap = (uint32_t)cap;
-        n_launches = n_iter + PTK_WF_MAX_LAG;  // a parked path runs at most this many launches behind its bounce number
+        n_launches = n_iter + ctx->wf_max_lag;  // a parked path runs at most this many launches behind its bounce number
     }
     if (!ctx->wf_ev[slot]) {
         ctx->wf_ev[slot] = new hipEvent_t[2 * PTK_WF_MAX_ITER];

@@ -40,7 +40,7 @@ struct PtkTexDesc {
 // in a parallel array that only the shading kernel touches; the hit record of
 // entry i is hits[i] = {hit, object_id, transform_index, bits(t)} and hit_uv[i].
 #define PTK_WF_MAX_ITER 64
-#define PTK_WF_MAX_LAG 2       // launches a path may fall behind its bounce number by being carried over (see PtkWavefront::carry)
+#define PTK_WF_MAX_LAG 8       // launches a path may fall behind its bounce number by being carried over (see PtkWavefront::carry)
 #define PTK_WF_CARRY_PLANES 25 // words of search state carried besides the stack rows
 // The top of many trees is a chain every ray walks in the same way: a root with one child, a mesh socket, a
 // mesh root with one child (scene root -> PTMesh socket -> mesh tree is the plugin's usual layout).  Those
@@ -68,6 +68,8 @@ struct PtkWavefront {
     uint32_t* carry[2];  // parked search state for the queue of that parity: [plane][carry_cap], PTK_WF_CARRY_PLANES planes
                          // then one per stack row of the LDS window; null = no carry-over
     uint32_t carry_cap;
+    int32_t max_lag;     // launches a path may be behind its bounce number (<= PTK_WF_MAX_LAG)
+    int32_t park_below;  // once the queue is dry, a wave parks its searches when at most this many are left (64: at once)
     float4* state[2];  // path state travelling with the queue entry, two float4 per entry:
                        // {throughput rgba}, {seed, current_IOR, bits(inside_of_count),
                        //  bits(refraction_bounces | inside-arrays-stored << 30)}

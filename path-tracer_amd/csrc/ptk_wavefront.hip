@@ -207,13 +207,16 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
     T.cur = ENTRY_NONE; T.sp = 0; T.sub_base = 0; T.cur_xf = -1;
     T.w_o = mk3(0, 0, 0); T.w_d = mk3(0, 0, 1); T.w_start = 0.0f; T.dir_len = 1.0f;
 
+    bool parked = false;  // this wave has parked its searches (what it could not park it finishes itself)
     for (;;) {
         const bool is_leaf = have && trav_is_leaf(T);
         const bool is_inner = have && trav_is_inner(T);
         const unsigned long long mi = __ballot(is_inner), ml = __ballot(is_leaf);
         const int n_idle = 64 - __popcll(mi | ml);
+        // the queue is dry and few searches are left in this wave: time to park them
+        const bool park_now = exhausted && carry_on && !parked && 64 - n_idle <= W.park_below;
 
-        if ((mi | ml) == 0ull || (!exhausted && n_idle >= PTK_WF_REFILL)) {
+        if ((mi | ml) == 0ull || park_now || (!exhausted && n_idle >= PTK_WF_REFILL)) {
             // ---- refill round: retire finished rays, claim new ones ----
 #ifdef PTK_WF_STATS
             if (lane == 0) atomicAdd(&g_wf_stats[271], 1ull);
@@ -253,10 +256,11 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
                 const uint32_t wanted = (uint32_t)__popcll(need);
                 c_next += wanted < avail ? wanted : avail;
             }
-            if (exhausted && carry_on) {
+            if (exhausted && carry_on && !parked && __popcll(__ballot(have)) <= W.park_below) {
                 // the queue is dry: park what is still searching, unless the path is too far behind already or
                 // part of its stack lives in the spill column
-                const bool park = have && T.cur != ENTRY_NONE && T.sp <= S.lds_cap && iter - ray_bounce < PTK_WF_MAX_LAG;
+                parked = true;
+                const bool park = have && T.cur != ENTRY_NONE && T.sp <= S.lds_cap && iter - ray_bounce < W.max_lag;
                 const unsigned long long pm = __ballot(park);
                 if (pm != 0ull) {
                     uint32_t base = 0;
