@@ -134,7 +134,7 @@ struct ptk_ctx {
     int n_cus = 0;
     int lds_window = 32;           // traversal stack entries per lane kept in LDS (PTK_LDS_WINDOW, read once at create)
     bool wf_carry = true;          // the pipeline parks unfinished searches for the next launch (PTK_WF_CARRY=0 turns it off; read once at create)
-    int wf_max_lag = 2, wf_park_below = 32;  // (PTK_WF_MAX_LAG, PTK_WF_PARK_BELOW: tuning, read once at create)
+    int wf_max_lag = 2, wf_park_below = 16;  // (PTK_WF_MAX_LAG, PTK_WF_PARK_BELOW: tuning, read once at create)
     void* d_wf_carry = nullptr;
     size_t wf_carry_bytes = 0;
     int waves_per_cu_cap = 0;      // > 0: upper bound on persistent waves per CU (PTK_WF_WAVES_PER_CU, read once at create)
@@ -845,7 +845,7 @@ static int validate_scene(ptk_ctx* ctx) {
         std::vector<int32_t> block_of((size_t)n_nodes, -1);
         uint32_t next_free = 0;
         {
-            const size_t stacks = (size_t)PTK_WF_WG_WAVES * (std::min(ctx->stack_need, ctx->lds_window) + 1) * 256;
+            const size_t stacks = (size_t)PTK_WF_WG_WAVES * (std::min(ctx->stack_need, ctx->lds_window) + 1) * 256 + PTK_WF_WG_FLAG_BYTES;
             const size_t room = PTK_LDS_BYTES_PER_CU > stacks ? (PTK_LDS_BYTES_PER_CU - stacks) / PTK_TOP_BLOCK_STRIDE : 0;
             const size_t limit = std::min<size_t>(room, 480);
             std::vector<std::pair<int, bool>> queue = {{0, false}};  // node, inside a mesh
@@ -945,7 +945,7 @@ static int validate_scene(ptk_ctx* ctx) {
     // persistent waves per CU of both persistent kernels at this scene's LDS need (window + one spare row)
     {
         const size_t lds = (size_t)(std::min(ctx->stack_need, ctx->lds_window) + 1) * 64 * 4;
-        HIP_TRY(ctx, ptk_wavefront_occupancy((size_t)ctx->n_top * PTK_TOP_BLOCK_STRIDE + PTK_WF_WG_WAVES * lds, &ctx->wf_wgs_per_cu));
+        HIP_TRY(ctx, ptk_wavefront_occupancy((size_t)ctx->n_top * PTK_TOP_BLOCK_STRIDE + PTK_WF_WG_WAVES * lds + PTK_WF_WG_FLAG_BYTES, &ctx->wf_wgs_per_cu));
         HIP_TRY(ctx, ptk_persistent_occupancy(lds, &ctx->pp_waves_per_cu));
         if (ctx->waves_per_cu_cap > 0) ctx->pp_waves_per_cu = std::min(ctx->pp_waves_per_cu, ctx->waves_per_cu_cap);
     }
@@ -1264,7 +1264,7 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         P.wf.tiles_x = groups_x;
     }
     // persistent traversal workgroups: as many as fit on the device at once
-    const size_t wf_lds = (size_t)ctx->n_top * PTK_TOP_BLOCK_STRIDE + (size_t)PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64 * 4;  // one spare row per wave
+    const size_t wf_lds = (size_t)ctx->n_top * PTK_TOP_BLOCK_STRIDE + (size_t)PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64 * 4 + PTK_WF_WG_FLAG_BYTES;  // one spare row per wave
     if (ctx->wf_wgs_per_cu <= 0) return fail(ctx, PTK_E_HIP, "the traversal kernel does not fit on a compute unit");
     const size_t wg_rays = (size_t)PTK_WF_WG_WAVES * 64;
     const int n_wgs = (int)std::min<size_t>((size_t)ctx->wf_wgs_per_cu * std::max(ctx->n_cus, 1), (n_slots + wg_rays - 1) / wg_rays);

@@ -41,6 +41,7 @@ struct PtkTexDesc {
 // entry i is hits[i] = {hit, object_id, transform_index, bits(t)} and hit_uv[i].
 #define PTK_WF_MAX_ITER 64
 #define PTK_WF_MAX_LAG 8       // launches a path may fall behind its bounce number by being carried over (see PtkWavefront::carry)
+#define PTK_WF_WG_FLAG_BYTES 16 // LDS words the waves of a traversal workgroup share besides the top blocks: queue dry, waves done
 #define PTK_WF_CARRY_PLANES 25 // words of search state carried besides the stack rows
 // The top of many trees is a chain every ray walks in the same way: a root with one child, a mesh socket, a
 // mesh root with one child (scene root -> PTMesh socket -> mesh tree is the plugin's usual layout).  Those

@@ -182,8 +182,12 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
         float4* top = (float4*)lds_all;
         for (uint32_t i = threadIdx.x; i < W.n_top * 16u; i += PTK_WF_WG_WAVES * 64)
             top[(i >> 4) * (PTK_TOP_BLOCK_STRIDE / 16) + (i & 15u)] = W.blocks[i];
+        if (threadIdx.x < PTK_WF_WG_FLAG_BYTES / 4) lds_all[W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64 + threadIdx.x] = 0;
         __syncthreads();  // the only workgroup-wide step: from here on every wave runs on its own
     }
+    // two words the waves of the workgroup tell each other through: [0] one of them found the queue dry,
+    // [1] how many have parked their searches or left
+    volatile int* const wg_flags = lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64;
     Stack S;
     S.top = (PtkLdsBlocks)lds_all; S.n_top = W.n_top;
     S.lds = lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + wave * (P.lds_cap + 1) * 64;
@@ -213,8 +217,12 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
         const bool is_inner = have && trav_is_inner(T);
         const unsigned long long mi = __ballot(is_inner), ml = __ballot(is_leaf);
         const int n_idle = 64 - __popcll(mi | ml);
-        // the queue is dry and few searches are left in this wave: time to park them
-        const bool park_now = exhausted && carry_on && !parked && 64 - n_idle <= W.park_below;
+        // The queue is dry (this wave found out at a refill, or another wave of the workgroup did) and few searches
+        // are left here, or half of the workgroup's waves are through: time to park what is left
+        // (a wave with part of a claimed chunk left still has rays to hand to its lanes)
+        if (carry_on && !exhausted && c_next == c_end && wg_flags[0] != 0) exhausted = true;
+        const bool park_now = exhausted && carry_on && !parked &&
+                              (64 - n_idle <= W.park_below || wg_flags[1] >= PTK_WF_WG_WAVES / 2);
 
         if ((mi | ml) == 0ull || park_now || (!exhausted && n_idle >= PTK_WF_REFILL)) {
             // ---- refill round: retire finished rays, claim new ones ----
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
                     base = __builtin_amdgcn_readfirstlane(base);
                     c_next = base < count ? base : count;
                     c_end = (base + WF_CHUNK) < count ? (base + WF_CHUNK) : count;
-                    if (c_next >= c_end) { exhausted = true; break; }
+                    if (c_next >= c_end) { exhausted = true; if (lane == 0) wg_flags[0] = 1; break; }
                 }
                 const uint32_t avail = c_end - c_next;
                 const uint32_t my = (uint32_t)lane_rank_in(need);
@@ -256,10 +264,11 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
                 const uint32_t wanted = (uint32_t)__popcll(need);
                 c_next += wanted < avail ? wanted : avail;
             }
-            if (exhausted && carry_on && !parked && __popcll(__ballot(have)) <= W.park_below) {
+            if (exhausted && carry_on && !parked && (__popcll(__ballot(have)) <= W.park_below || wg_flags[1] >= PTK_WF_WG_WAVES / 2)) {
                 // the queue is dry: park what is still searching, unless the path is too far behind already or
                 // part of its stack lives in the spill column
                 parked = true;
+                if (lane == 0) atomicAdd((int*)wg_flags + 1, 1);
                 const bool park = have && T.cur != ENTRY_NONE && T.sp <= S.lds_cap && iter - ray_bounce < W.max_lag;
                 const unsigned long long pm = __ballot(park);
                 if (pm != 0ull) {
@@ -275,7 +284,10 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
                     }
                 }
             }
-            if (exhausted && __ballot(have) == 0ull) break;
+            if (exhausted && __ballot(have) == 0ull) {
+                if (!parked && lane == 0) atomicAdd((int*)wg_flags + 1, 1);
+                break;
+            }
             continue;
         }
 
