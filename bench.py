@@ -16,7 +16,8 @@ the GPU, and passes the ranks' output through.  On a box with fewer than N GPUs 
 talk over gloo (a rehearsal of the control flow, marked "rehearsal": true in the line).
 
 A step is rendered by the wavefront pipeline: one generate launch, then per bounce one traversal
-launch (ptk_wf_traverse, the dominant kernel) and one shading launch.
+launch (ptk_wf_traverse, the dominant kernel) and one shading launch; searches still under way when a
+launch's queue runs dry are carried over to the next launch, which adds two short launches at the end.
 
 Rank 0 prints one JSON line; see the keys "roofline" (the traversal kernel: algorithmic bytes of the
 closest-hit searches / its measured launch durations, against the 8 TB/s HBM peak; "step" repeats the
@@ -329,6 +330,8 @@ def main():
             "hbm_measured": None if traffic is None else {"bytes_per_launch": traffic, "gbs": traffic / (avg_launch_ms * 1e-3) / 1e9,
                                                           "frac_of_peak": traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "limiter": limiter_note(),
+            "note": "achieved prices every box and primitive test at the reference layout's bytes with no cache credit, as the metric is defined; "
+                    "the scene's tree stays in LDS / L2, so the figure can pass the HBM peak (frac > 1): hbm_measured is what the memory side moved",
             "bytes_per_launch": trav_bytes_per_launch,
             "launch_ms_avg": avg_launch_ms,
             "launches_per_step": launches_per_step,
