@@ -138,7 +138,7 @@ struct ptk_ctx {
     void* d_wf_carry = nullptr;
     size_t wf_carry_bytes = 0;
     int waves_per_cu_cap = 0;      // > 0: upper bound on persistent waves per CU (PTK_WF_WAVES_PER_CU, read once at create)
-    int wf_wgs_per_cu = 0, pp_waves_per_cu = 0;  // occupancy of the two persistent kernels for the bound scene's LDS need
+    int wf_wgs_per_cu = 0, pp_wgs_per_cu = 0, pp_wg_waves = 0;  // occupancy of the two persistent kernels for the bound scene's LDS need
     uint32_t n_top = 0;            // blocks [0, n_top): top of the tree, breadth-first, LDS-resident in the traversal kernel
     hipEvent_t* wf_ev[kTimingRing] = {nullptr};  // per dispatch slot: 2 events per traversal launch
     int wf_iters[kTimingRing] = {0};            // traversal launches of that dispatch (0: one-kernel renderer)
@@ -946,8 +946,9 @@ static int validate_scene(ptk_ctx* ctx) {
     {
         const size_t lds = (size_t)(std::min(ctx->stack_need, ctx->lds_window) + 1) * 64 * 4;
         HIP_TRY(ctx, ptk_wavefront_occupancy((size_t)ctx->n_top * PTK_TOP_BLOCK_STRIDE + PTK_WF_WG_WAVES * lds + PTK_WF_WG_FLAG_BYTES, &ctx->wf_wgs_per_cu));
-        HIP_TRY(ctx, ptk_persistent_occupancy(lds, &ctx->pp_waves_per_cu));
-        if (ctx->waves_per_cu_cap > 0) ctx->pp_waves_per_cu = std::min(ctx->pp_waves_per_cu, ctx->waves_per_cu_cap);
+        HIP_TRY(ctx, ptk_persistent_occupancy(lds, ctx->n_top, &ctx->pp_wg_waves, &ctx->pp_wgs_per_cu));
+        if (ctx->waves_per_cu_cap > 0 && ctx->pp_wg_waves > 0)
+            ctx->pp_wgs_per_cu = std::max(1, std::min(ctx->pp_wgs_per_cu, ctx->waves_per_cu_cap / ctx->pp_wg_waves));
     }
     ctx->dirty = false;
     ctx->full_validations++;
@@ -1209,9 +1210,10 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
 
     if (choice == 2) {
         const size_t pp_lds = (size_t)(P.lds_cap + 1) * 64 * 4;  // one spare row for rejected children
-        const int waves_per_cu = ctx->pp_waves_per_cu;
-        if (waves_per_cu <= 0) return fail(ctx, PTK_E_HIP, "the path kernel does not fit on a compute unit");
-        const int n_waves = (int)std::min<size_t>((size_t)waves_per_cu * std::max(ctx->n_cus, 1), (lanes + 63) / 64);
+        if (ctx->pp_wgs_per_cu <= 0) return fail(ctx, PTK_E_HIP, "the path kernel does not fit on a compute unit");
+        const size_t wg_lanes = (size_t)ctx->pp_wg_waves * 64;
+        const int n_wgs = (int)std::min<size_t>((size_t)ctx->pp_wgs_per_cu * std::max(ctx->n_cus, 1), (lanes + wg_lanes - 1) / wg_lanes);
+        const int n_waves = n_wgs * ctx->pp_wg_waves;
         if (!ctx->d_pixel_counter) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pixel_counter, 256));
         P.wf.heads = ctx->d_pixel_counter;
         P.wf.n_slots = (uint32_t)lanes;
@@ -1231,7 +1233,7 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         }
         ctx->wf_iters[slot] = 0;
         HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
-        HIP_TRY(ctx, ptk_launch_persistent(&P, pp_lds, n_waves, ctx->stream));
+        HIP_TRY(ctx, ptk_launch_persistent(&P, pp_lds, n_wgs, ctx->pp_wg_waves, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
         ctx->dispatch_count++;
         return PTK_OK;
@@ -1337,8 +1339,10 @@ int ptk_dispatch_noalloc(ptk_ctx* ctx, const void* push128, int groups_x, int gr
     fill_blocks(ctx, P);
     P.lds_cap = std::min(ctx->stack_need, ctx->lds_window);
     const size_t pp_lds = (size_t)(P.lds_cap + 1) * 64 * 4;
-    if (ctx->pp_waves_per_cu <= 0) return fail(ctx, PTK_E_HIP, "the path kernel does not fit on a compute unit");
-    size_t n_waves = std::min<size_t>((size_t)ctx->pp_waves_per_cu * std::max(ctx->n_cus, 1), (lanes + 63) / 64);
+    if (ctx->pp_wgs_per_cu <= 0) return fail(ctx, PTK_E_HIP, "the path kernel does not fit on a compute unit");
+    const size_t wg_waves = (size_t)ctx->pp_wg_waves;
+    size_t n_wgs = std::min<size_t>((size_t)ctx->pp_wgs_per_cu * std::max(ctx->n_cus, 1), (lanes + wg_waves * 64 - 1) / (wg_waves * 64));
+    size_t n_waves = n_wgs * wg_waves;
     // stack entries past the LDS window: one int per entry and lane, [entry][wave * 64 + lane], behind the counter line
     const int spill_entries = ctx->stack_need - P.lds_cap;
     const size_t spill_room = PTK_NOALLOC_SCRATCH_BYTES - 256;
@@ -1346,12 +1350,13 @@ int ptk_dispatch_noalloc(ptk_ctx* ctx, const void* push128, int groups_x, int gr
         // fewer persistent waves need a smaller column (the image does not depend on their number), but
         // below one wave per compute unit the dispatch is refused rather than crawled through
         const size_t fit = spill_room / ((size_t)spill_entries * 64 * 4);
-        const size_t floor_waves = std::min<size_t>((size_t)std::max(ctx->n_cus, 1), (lanes + 63) / 64);
+        const size_t floor_waves = std::max(wg_waves, std::min<size_t>((size_t)std::max(ctx->n_cus, 1), (lanes + 63) / 64));
         if (fit < floor_waves)
             return fail(ctx, PTK_E_UNSUPPORTED, "the bound BVH can need %d traversal-stack entries per ray; the static scratch of %zu bytes "
                                                 "holds at most %zu beyond the %d kept on chip for this dispatch: use ptk_dispatch",
                         ctx->stack_need, (size_t)PTK_NOALLOC_SCRATCH_BYTES, spill_room / (floor_waves * 64 * 4), P.lds_cap);
-        n_waves = std::min(n_waves, fit);
+        n_wgs = std::min(n_wgs, fit / wg_waves);  // whole workgroups
+        n_waves = n_wgs * wg_waves;
         P.spill = (int*)(scratch_ptr + 256);
     }
     P.spill_stride = n_waves * 64;
@@ -1361,7 +1366,7 @@ int ptk_dispatch_noalloc(ptk_ctx* ctx, const void* push128, int groups_x, int gr
     const int slot = (int)(ctx->dispatch_count % ptk_ctx::kTimingRing);
     ctx->wf_iters[slot] = 0;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
-    HIP_TRY(ctx, ptk_launch_persistent(&P, pp_lds, (int)n_waves, ctx->stream));
+    HIP_TRY(ctx, ptk_launch_persistent(&P, pp_lds, (int)n_wgs, ctx->pp_wg_waves, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
     ctx->dispatch_count++;
     return PTK_OK;

@@ -41,6 +41,7 @@ struct PtkTexDesc {
 // entry i is hits[i] = {hit, object_id, transform_index, bits(t)} and hit_uv[i].
 #define PTK_WF_MAX_ITER 64
 #define PTK_WF_MAX_LAG 8       // launches a path may fall behind its bounce number by being carried over (see PtkWavefront::carry)
+#define PTK_PP_MAX_WG_WAVES 12  // waves of a path-kernel workgroup (three per SIMD at its register count)
 #define PTK_WF_WG_FLAG_BYTES 16 // LDS words the waves of a traversal workgroup share besides the top blocks: queue dry, waves done
 #define PTK_WF_CARRY_PLANES 25 // words of search state carried besides the stack rows
 // The top of many trees is a chain every ray walks in the same way: a root with one child, a mesh socket, a
@@ -137,8 +138,11 @@ extern "C" hipError_t ptk_launch_wavefront(const PtkParams* p, int gx, int gy, i
 #define PTK_LDS_BYTES_PER_CU 163840
 #define PTK_TOP_BLOCK_STRIDE 272  /* bytes between top blocks in LDS: 256 + 16, so that lanes on different blocks spread over the banks */
 extern "C" hipError_t ptk_wavefront_occupancy(size_t lds_bytes, int* wgs_per_cu);
-extern "C" hipError_t ptk_launch_persistent(const PtkParams* p, size_t lds_bytes, int n_waves, hipStream_t stream);
-extern "C" hipError_t ptk_persistent_occupancy(size_t lds_bytes, int* waves_per_cu);
+// The path kernel runs in workgroups of wg_waves waves that share an LDS copy of the top node blocks (as the
+// traversal kernel's do).  lds_per_wave: the wave's stack window; the launch takes n_wgs workgroups.
+extern "C" hipError_t ptk_launch_persistent(const PtkParams* p, size_t lds_per_wave, int n_wgs, int wg_waves, hipStream_t stream);
+// Picks the largest workgroup (12, 8, 4, 2 or 1 waves) that fits a compute unit with n_top top blocks in LDS.
+extern "C" hipError_t ptk_persistent_occupancy(size_t lds_per_wave, uint32_t n_top, int* wg_waves, int* wgs_per_cu);
 // Static device scratch of ptk_dispatch_noalloc (a file-scope __device__ array in ptk_persistent.hip):
 // [0, 256) pixel counter, the rest traversal-stack spill.  _init resolves the current device's copy once.
 #define PTK_NOALLOC_SCRATCH_BYTES ((size_t)8 << 20)

@@ -38,13 +38,23 @@ enum : int { PP_IDLE = 0, PP_SEARCH = 1, PP_HIT = 2 };
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void ptk_path_kernel(const PtkParams P) {
-    extern __shared__ int lds_stack[];  // [entry][lane], P.lds_cap rows + one spare row
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(PTK_PP_MAX_WG_WAVES * 64) void ptk_path_kernel(const PtkParams P) {
+    // [top blocks: n_top * 272 bytes][per wave: stack window [entry][lane], P.lds_cap rows + one spare row]
+    extern __shared__ __attribute__((aligned(16))) int lds_all[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wg_waves = (int)(blockDim.x >> 6);
     const PtkWavefront& W = P.wf;
+    {
+        // the waves of a workgroup share one thing: the LDS copy of the top of the block tree
+        float4* top = (float4*)lds_all;
+        for (uint32_t i = threadIdx.x; i < W.n_top * 16u; i += blockDim.x)
+            top[(i >> 4) * (PTK_TOP_BLOCK_STRIDE / 16) + (i & 15u)] = W.blocks[i];
+        __syncthreads();
+    }
     Stack S;
-    S.lds = lds_stack; S.lane = lane; S.lds_cap = P.lds_cap; S.spill_stride = P.spill_stride;
-    S.spill = P.spill ? P.spill + (size_t)blockIdx.x * 64 + lane : nullptr;
+    S.top = (PtkLdsBlocks)lds_all; S.n_top = W.n_top;
+    S.lds = lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + wave * (P.lds_cap + 1) * 64;
+    S.lane = lane; S.lds_cap = P.lds_cap; S.spill_stride = P.spill_stride;
+    S.spill = P.spill ? P.spill + ((size_t)blockIdx.x * wg_waves + wave) * 64 + lane : nullptr;
 
     const uint32_t n_slots = W.n_slots;  // pixel slots, tile-major: slot >> 6 = 8x8 tile, slot & 63 = pixel in it
     uint32_t c_next = 0, c_end = 0;      // this wave's claimed range of slots
@@ -211,19 +221,29 @@ extern "C" void* ptk_persistent_scratch(int device) {
     return g_scratch_ptr[device];
 }
 
-extern "C" hipError_t ptk_persistent_occupancy(size_t lds_bytes, int* waves_per_cu) {
-    int n = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ptk_path_kernel, 64, lds_bytes);
+extern "C" hipError_t ptk_persistent_occupancy(size_t lds_per_wave, uint32_t n_top, int* wg_waves, int* wgs_per_cu) {
+    // a workgroup may use up to the whole 160 KiB of a compute unit
+    hipError_t e = hipFuncSetAttribute((const void*)ptk_path_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PTK_LDS_BYTES_PER_CU);
     if (e != hipSuccess) return e;
-    *waves_per_cu = n;
+    *wg_waves = 0;
+    *wgs_per_cu = 0;
+    for (int w : {PTK_PP_MAX_WG_WAVES, 8, 4, 2, 1}) {
+        const size_t lds = (size_t)n_top * PTK_TOP_BLOCK_STRIDE + (size_t)w * lds_per_wave;
+        if (lds > PTK_LDS_BYTES_PER_CU) continue;
+        int n = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ptk_path_kernel, w * 64, lds);
+        if (e != hipSuccess) return e;
+        if (n > 0) { *wg_waves = w; *wgs_per_cu = n; return hipSuccess; }
+    }
     return hipSuccess;
 }
 
 // p->wf.heads points at the pixel counter (the first word of a 256-byte line, cleared here); p->wf.n_slots /
 // tiles_x describe the dispatch; p->wf.blocks etc. the compiled scene.
-extern "C" hipError_t ptk_launch_persistent(const PtkParams* p, size_t lds_bytes, int n_waves, hipStream_t stream) {
+extern "C" hipError_t ptk_launch_persistent(const PtkParams* p, size_t lds_per_wave, int n_wgs, int wg_waves, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(p->wf.heads, 0, 256, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ptk_path_kernel, dim3((unsigned)n_waves), dim3(64), lds_bytes, stream, *p);
+    const size_t lds = (size_t)p->wf.n_top * PTK_TOP_BLOCK_STRIDE + (size_t)wg_waves * lds_per_wave;
+    hipLaunchKernelGGL(ptk_path_kernel, dim3((unsigned)n_wgs), dim3((unsigned)wg_waves * 64), lds, stream, *p);
     return hipGetLastError();
 }
