@@ -135,6 +135,7 @@ struct ptk_ctx {
     int lds_window = 32;           // traversal stack entries per lane kept in LDS (PTK_LDS_WINDOW, read once at create)
     bool wf_carry = true;          // the pipeline parks unfinished searches for the next launch (PTK_WF_CARRY=0 turns it off; read once at create)
     int wf_max_lag = 2, wf_park_below = 16;  // (PTK_WF_MAX_LAG, PTK_WF_PARK_BELOW: tuning, read once at create)
+    int wf_wg_claim = 0;           // queue entries per workgroup claim; 0: chosen per scene (PTK_WF_WG_CLAIM, read once at create)
     void* d_wf_carry = nullptr;
     size_t wf_carry_bytes = 0;
     int waves_per_cu_cap = 0;      // > 0: upper bound on persistent waves per CU (PTK_WF_WAVES_PER_CU, read once at create)
@@ -221,6 +222,7 @@ ptk_ctx* ptk_create(int device_ordinal) {
     if (const char* w = getenv("PTK_WF_CARRY")) ctx->wf_carry = atoi(w) != 0;
     if (const char* w = getenv("PTK_WF_MAX_LAG")) ctx->wf_max_lag = std::max(1, std::min(PTK_WF_MAX_LAG, atoi(w)));
     if (const char* w = getenv("PTK_WF_PARK_BELOW")) ctx->wf_park_below = std::max(1, std::min(64, atoi(w)));
+    if (const char* w = getenv("PTK_WF_WG_CLAIM")) ctx->wf_wg_claim = std::max(1, std::min(64, atoi(w) / 64)) * 64;
     if (const char* c = getenv("PTK_WF_WAVES_PER_CU")) ctx->waves_per_cu_cap = std::max(1, atoi(c));
     if (!ok) {
         fail(nullptr, PTK_E_HIP, "stream/event creation failed");
@@ -1290,7 +1292,12 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     P.wf.carry_cap = 0;
     P.wf.max_lag = ctx->wf_max_lag;
     P.wf.park_below = ctx->wf_park_below;
-    if (ctx->wf_carry && n_iter > 1 && n_iter + ctx->wf_max_lag <= PTK_WF_MAX_ITER) {
+    // What a workgroup has taken no other can take, so small claims even out the end of a launch; but the device-wide
+    // counter serves one atomic at a time (~12 ns), which is what limits a launch over a tree that sits in LDS as a whole.
+    P.wf.wg_claim = ctx->wf_wg_claim > 0 ? (uint32_t)ctx->wf_wg_claim : (ctx->n_blocks > ctx->n_top ? 256u : (uint32_t)PTK_WF_WG_WAVES * 64u);
+    // (not for a tree that sits in LDS as a whole: its searches are short, and parking costs each wave a
+    // device-wide atomic and the step two more launches)
+    if (ctx->wf_carry && n_iter > 1 && n_iter + ctx->wf_max_lag <= PTK_WF_MAX_ITER && ctx->n_blocks > ctx->n_top) {
         const size_t cap = n_waves * 64;
         const size_t bytes = (size_t)(PTK_WF_CARRY_PLANES + P.lds_cap) * cap * 4;
         if (2 * bytes > ctx->wf_carry_bytes) {

@@ -20,11 +20,15 @@
 
 namespace {
 
-constexpr uint32_t PP_CHUNK = 64;  // pixels a wave claims per atomic
 #ifndef PTK_PP_BOUNCE_NOW
 // a bounce round runs once the lanes waiting for their bounce are as many as the lanes still searching
 // (the same majority rule as between inner and leaf rounds); measured against fixed thresholds of 16..64
 #define PTK_PP_BOUNCE_NOW(n_hit, n_search) ((n_hit) >= (n_search))
+#endif
+#ifndef PTK_PP_CLAIM_PER_WAVE
+#define PTK_PP_CLAIM_PER_WAVE 16u  // pixel slots a workgroup takes from the device-wide counter at a time, per wave of it
+                                   // (measured 64 / 32 / 16 on the 262 144-triangle scene: 14.9 / 14.5 / 14.4 ms; what a
+                                   // workgroup holds nobody else can take, which lengthens the end of the launch)
 #endif
 #ifndef PTK_PP_REFILL
 #define PTK_PP_REFILL 16           // idle lanes that make the wave run a refill round
@@ -39,7 +43,7 @@ enum : int { PP_IDLE = 0, PP_SEARCH = 1, PP_HIT = 2 };
 }  // namespace
 
 __global__ __launch_bounds__(PTK_PP_MAX_WG_WAVES * 64) void ptk_path_kernel(const PtkParams P) {
-    // [top blocks: n_top * 272 bytes][per wave: stack window [entry][lane], P.lds_cap rows + one spare row]
+    // [top blocks: n_top * 272 bytes][per wave: stack window [entry][lane], P.lds_cap rows + one spare row][16 bytes: claim word]
     extern __shared__ __attribute__((aligned(16))) int lds_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wg_waves = (int)(blockDim.x >> 6);
     const PtkWavefront& W = P.wf;
@@ -48,8 +52,11 @@ __global__ __launch_bounds__(PTK_PP_MAX_WG_WAVES * 64) void ptk_path_kernel(cons
         float4* top = (float4*)lds_all;
         for (uint32_t i = threadIdx.x; i < W.n_top * 16u; i += blockDim.x)
             top[(i >> 4) * (PTK_TOP_BLOCK_STRIDE / 16) + (i & 15u)] = W.blocks[i];
+        if (threadIdx.x < PTK_WF_WG_FLAG_BYTES / 4) lds_all[W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + wg_waves * (P.lds_cap + 1) * 64 + threadIdx.x] = 0;
         __syncthreads();
     }
+    // the workgroup's chunk of the pixel slots (see wg_claim), behind the stack windows
+    unsigned long long* const wg_range = (unsigned long long*)(lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + wg_waves * (P.lds_cap + 1) * 64);
     Stack S;
     S.top = (PtkLdsBlocks)lds_all; S.n_top = W.n_top;
     S.lds = lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + wave * (P.lds_cap + 1) * 64;
@@ -58,6 +65,7 @@ __global__ __launch_bounds__(PTK_PP_MAX_WG_WAVES * 64) void ptk_path_kernel(cons
 
     const uint32_t n_slots = W.n_slots;  // pixel slots, tile-major: slot >> 6 = 8x8 tile, slot & 63 = pixel in it
     uint32_t c_next = 0, c_end = 0;      // this wave's claimed range of slots
+    const uint32_t wg_chunk = ((uint32_t)wg_waves * PTK_PP_CLAIM_PER_WAVE) / 64u > 0u ? ((uint32_t)wg_waves * PTK_PP_CLAIM_PER_WAVE) / 64u * 64u : 64u;  // a multiple of 64
     bool exhausted = n_slots == 0;
 
     int phase = PP_IDLE;
@@ -140,12 +148,9 @@ __global__ __launch_bounds__(PTK_PP_MAX_WG_WAVES * 64) void ptk_path_kernel(cons
                 const unsigned long long need = __ballot(phase == PP_IDLE);
                 if (need == 0ull) break;
                 if (c_next == c_end) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(W.heads, PP_CHUNK);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    c_next = base < n_slots ? base : n_slots;
-                    c_end = (base + PP_CHUNK) < n_slots ? (base + PP_CHUNK) : n_slots;
-                    if (c_next >= c_end) { exhausted = true; break; }
+                    const int got = wg_claim(wg_range, W.heads, wg_chunk, n_slots, lane, c_next, c_end);
+                    if (got == CLAIM_DRY) { exhausted = true; break; }
+                    if (got == CLAIM_LATER) { __builtin_amdgcn_s_sleep(1); break; }  // another wave is fetching the workgroup's next chunk
                 }
                 const uint32_t avail = c_end - c_next;
                 const uint32_t my = (uint32_t)pp_rank_in(need);
@@ -228,7 +233,7 @@ extern "C" hipError_t ptk_persistent_occupancy(size_t lds_per_wave, uint32_t n_t
     *wg_waves = 0;
     *wgs_per_cu = 0;
     for (int w : {PTK_PP_MAX_WG_WAVES, 8, 4, 2, 1}) {
-        const size_t lds = (size_t)n_top * PTK_TOP_BLOCK_STRIDE + (size_t)w * lds_per_wave;
+        const size_t lds = (size_t)n_top * PTK_TOP_BLOCK_STRIDE + (size_t)w * lds_per_wave + PTK_WF_WG_FLAG_BYTES;
         if (lds > PTK_LDS_BYTES_PER_CU) continue;
         int n = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ptk_path_kernel, w * 64, lds);
@@ -243,7 +248,7 @@ extern "C" hipError_t ptk_persistent_occupancy(size_t lds_per_wave, uint32_t n_t
 extern "C" hipError_t ptk_launch_persistent(const PtkParams* p, size_t lds_per_wave, int n_wgs, int wg_waves, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(p->wf.heads, 0, 256, stream);
     if (e != hipSuccess) return e;
-    const size_t lds = (size_t)p->wf.n_top * PTK_TOP_BLOCK_STRIDE + (size_t)wg_waves * lds_per_wave;
+    const size_t lds = (size_t)p->wf.n_top * PTK_TOP_BLOCK_STRIDE + (size_t)wg_waves * lds_per_wave + PTK_WF_WG_FLAG_BYTES;
     hipLaunchKernelGGL(ptk_path_kernel, dim3((unsigned)n_wgs), dim3((unsigned)wg_waves * 64), lds, stream, *p);
     return hipGetLastError();
 }

@@ -246,6 +246,46 @@ PTK_DEV int st_read(const Stack& s, int i) {
     return s.spill ? s.spill[(size_t)(i - s.lds_cap) * s.spill_stride] : 0;
 }
 
+// ---- work claims of a workgroup's waves ---------------------------------------------------------
+// Queue entries (or pixel slots) are handed out in two steps: a workgroup takes `wg_chunk` entries (64 for each
+// of its waves: the last workgroup to get any then has one piece per wave, as with claims by the wave) from the
+// device-wide counter with one global atomic, its waves take 64 at a time from that with an LDS atomic.
+// Device-wide atomics on one address complete one after the other, about 12 ns each on this part: at 64 entries
+// per atomic that alone holds a launch to ~5 G entries/s, and every wave's last, futile claim adds another.
+// `range` is one 64-bit LDS word, low half = next entry to hand out, high half = end of the workgroup's
+// chunk, zero at the start (next == end).  Every add returns a different `next`, so exactly one wave sees
+// next == end: that one fetches the workgroup's next chunk, keeps its first 64 entries and publishes the rest
+// with one 64-bit store; waves that come past the end meanwhile try again at their next refill round.  The
+// wave that finds the device-wide counter past `count` leaves that as a mark in the word.
+enum : int { CLAIM_OK = 0, CLAIM_LATER = 1, CLAIM_DRY = 2 };
+PTK_DEV int wg_claim(unsigned long long* range, uint32_t* head, uint32_t wg_chunk, uint32_t count, int lane, uint32_t& c_next, uint32_t& c_end) {
+    uint32_t nx = 0, en = 0;
+    if (lane == 0) {
+        const unsigned long long old = __hip_atomic_fetch_add(range, 64ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        nx = (uint32_t)old; en = (uint32_t)(old >> 32);
+    }
+    nx = __builtin_amdgcn_readfirstlane(nx);
+    en = __builtin_amdgcn_readfirstlane(en);
+    if (nx == en) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(head, wg_chunk);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= count) {  // leave word of it for the others: a `next` no queue reaches, past an end of zero
+            if (lane == 0) __hip_atomic_store(range, 0x80000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return CLAIM_DRY;
+        }
+        if (lane == 0) __hip_atomic_store(range, ((unsigned long long)(base + wg_chunk) << 32) | (unsigned long long)(base + 64u),
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        nx = base;
+    } else if (nx > en) {
+        return nx >= 0x80000000u ? CLAIM_DRY : CLAIM_LATER;
+    }
+    if (nx >= count) return CLAIM_DRY;
+    c_next = nx;
+    c_end = nx + 64u < count ? nx + 64u : count;
+    return CLAIM_OK;
+}
+
 // Closest hit over planes + BVH, :1200-1320 with :1115-1198 folded into one loop.
 template <bool TRACE, bool EARLY_T>
 PTK_DEV Hit check_ray_hit_bvh(const PtkParams& P, Lane& L, Ray& ray, const Stack& S, const Stack& ST, int* cnt) {

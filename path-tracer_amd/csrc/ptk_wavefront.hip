@@ -23,7 +23,6 @@
 namespace {
 
 constexpr int SHADE_BLOCK = 512;    // threads per shading block (one queue reservation per block)
-constexpr uint32_t WF_CHUNK = 64;  // rays a wave claims from the queue per atomic
 #ifndef PTK_WF_VOTE_INNER
 #define PTK_WF_VOTE_INNER(ni, nl) ((ni) >= (nl))  // which kind of round runs next: the larger group's
 #endif
@@ -185,9 +184,10 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
         if (threadIdx.x < PTK_WF_WG_FLAG_BYTES / 4) lds_all[W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64 + threadIdx.x] = 0;
         __syncthreads();  // the only workgroup-wide step: from here on every wave runs on its own
     }
-    // two words the waves of the workgroup tell each other through: [0] one of them found the queue dry,
-    // [1] how many have parked their searches or left
+    // words the waves of the workgroup tell each other through: [0] one of them found the queue dry,
+    // [1] how many have parked their searches or left, [2..3] the workgroup's chunk of the queue
     volatile int* const wg_flags = lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64;
+    unsigned long long* const wg_range = (unsigned long long*)(lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64 + 2);  // see wg_claim
     Stack S;
     S.top = (PtkLdsBlocks)lds_all; S.n_top = W.n_top;
     S.lds = lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + wave * (P.lds_cap + 1) * 64;
@@ -239,12 +239,9 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
                 const unsigned long long need = __ballot(!have);
                 if (need == 0ull) break;
                 if (c_next == c_end) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(W.heads + iter, WF_CHUNK);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    c_next = base < count ? base : count;
-                    c_end = (base + WF_CHUNK) < count ? (base + WF_CHUNK) : count;
-                    if (c_next >= c_end) { exhausted = true; if (lane == 0) wg_flags[0] = 1; break; }
+                    const int got = wg_claim(wg_range, W.heads + iter, W.wg_claim, count, lane, c_next, c_end);
+                    if (got == CLAIM_DRY) { exhausted = true; if (lane == 0) wg_flags[0] = 1; break; }
+                    if (got == CLAIM_LATER) { __builtin_amdgcn_s_sleep(1); break; }  // another wave is fetching the workgroup's next chunk
                 }
                 const uint32_t avail = c_end - c_next;
                 const uint32_t my = (uint32_t)lane_rank_in(need);
