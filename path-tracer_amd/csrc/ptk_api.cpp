@@ -1294,7 +1294,7 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     P.wf.park_below = ctx->wf_park_below;
     // What a workgroup has taken no other can take, so small claims even out the end of a launch; but the device-wide
     // counter serves one atomic at a time (~12 ns), which is what limits a launch over a tree that sits in LDS as a whole.
-    P.wf.wg_claim = ctx->wf_wg_claim > 0 ? (uint32_t)ctx->wf_wg_claim : (ctx->n_blocks > ctx->n_top ? 256u : (uint32_t)PTK_WF_WG_WAVES * 64u);
+    P.wf.wg_claim = ctx->wf_wg_claim > 0 ? (uint32_t)ctx->wf_wg_claim : (ctx->n_blocks > ctx->n_top ? 256u : 512u);
     // (not for a tree that sits in LDS as a whole: its searches are short, and parking costs each wave a
     // device-wide atomic and the step two more launches)
     if (ctx->wf_carry && n_iter > 1 && n_iter + ctx->wf_max_lag <= PTK_WF_MAX_ITER && ctx->n_blocks > ctx->n_top) {

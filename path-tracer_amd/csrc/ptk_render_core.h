@@ -267,9 +267,11 @@ PTK_DEV int wg_claim(unsigned long long* range, uint32_t* head, uint32_t wg_chun
     nx = __builtin_amdgcn_readfirstlane(nx);
     en = __builtin_amdgcn_readfirstlane(en);
     if (nx == en) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(head, wg_chunk);
-        base = __builtin_amdgcn_readfirstlane(base);
+        uint32_t base = count;  // (no counter: the workgroup's one chunk was set at the start, and this is its end)
+        if (head) {
+            if (lane == 0) base = atomicAdd(head, wg_chunk);
+            base = __builtin_amdgcn_readfirstlane(base);
+        }
         if (base >= count) {  // leave word of it for the others: a `next` no queue reaches, past an end of zero
             if (lane == 0) __hip_atomic_store(range, 0x80000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             return CLAIM_DRY;

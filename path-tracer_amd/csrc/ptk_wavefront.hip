@@ -177,11 +177,25 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
     const size_t ends_at = ((size_t)iter * PTK_WF_ENDS_WAVES + blockIdx.x * PTK_WF_WG_WAVES + wave) * 2;
     if (lane == 0 && iter < PTK_WF_ENDS_ITERS) g_wf_ends[ends_at] = wall_clock64();
 #endif
+    const uint32_t n_res = __builtin_amdgcn_readfirstlane(W.n_resume[iter]);  // parked searches at the queue's front
+    const uint32_t count = n_res + __builtin_amdgcn_readfirstlane(W.counts[iter]);
+    // A queue with no more than one chunk for every workgroup is dealt out by position, without the device-wide counter
+    const bool dealt = count <= gridDim.x * W.wg_claim;
+    if (count == 0 || (dealt && blockIdx.x * W.wg_claim >= count)) {  // nothing for this workgroup
+#ifdef PTK_WF_ENDS
+        if (lane == 0 && iter < PTK_WF_ENDS_ITERS) g_wf_ends[ends_at + 1] = wall_clock64();
+#endif
+        return;
+    }
     {
         float4* top = (float4*)lds_all;
         for (uint32_t i = threadIdx.x; i < W.n_top * 16u; i += PTK_WF_WG_WAVES * 64)
             top[(i >> 4) * (PTK_TOP_BLOCK_STRIDE / 16) + (i & 15u)] = W.blocks[i];
-        if (threadIdx.x < PTK_WF_WG_FLAG_BYTES / 4) lds_all[W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64 + threadIdx.x] = 0;
+        if (threadIdx.x < PTK_WF_WG_FLAG_BYTES / 4) {
+            int v = 0;
+            if (dealt && threadIdx.x >= 2) v = (int)((blockIdx.x + (threadIdx.x - 2)) * W.wg_claim);  // [2] next = the chunk's start, [3] its end
+            lds_all[W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64 + threadIdx.x] = v;
+        }
         __syncthreads();  // the only workgroup-wide step: from here on every wave runs on its own
     }
     // words the waves of the workgroup tell each other through: [0] one of them found the queue dry,
@@ -194,12 +208,10 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
     S.lane = lane; S.lds_cap = P.lds_cap; S.spill_stride = P.spill_stride;
     S.spill = P.spill ? P.spill + ((size_t)blockIdx.x * PTK_WF_WG_WAVES + wave) * 64 + lane : nullptr;
 
-    const uint32_t n_res = __builtin_amdgcn_readfirstlane(W.n_resume[iter]);  // parked searches at the queue's front
-    const uint32_t count = n_res + __builtin_amdgcn_readfirstlane(W.counts[iter]);
     const float4* __restrict__ rq = W.rays[iter & 1];
     const bool carry_on = W.carry[0] != nullptr;
     uint32_t c_next = 0, c_end = 0;  // this wave's claimed queue range
-    bool exhausted = count == 0;
+    bool exhausted = false;
 
     bool have = false;  // the lane holds a ray
     uint32_t ray_idx = 0;
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
                 const unsigned long long need = __ballot(!have);
                 if (need == 0ull) break;
                 if (c_next == c_end) {
-                    const int got = wg_claim(wg_range, W.heads + iter, W.wg_claim, count, lane, c_next, c_end);
+                    const int got = wg_claim(wg_range, dealt ? nullptr : W.heads + iter, W.wg_claim, count, lane, c_next, c_end);
                     if (got == CLAIM_DRY) { exhausted = true; if (lane == 0) wg_flags[0] = 1; break; }
                     if (got == CLAIM_LATER) { __builtin_amdgcn_s_sleep(1); break; }  // another wave is fetching the workgroup's next chunk
                 }
