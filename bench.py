@@ -176,6 +176,8 @@ def main():
     rd.trace_enable(0)
     # AUTO would spend its first four dispatches timing both schedules; the bench pins the pipeline it reports on
     rd.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
+    # events around every traversal launch of the timed steps: the roofline's launch duration is measured live
+    rd.set_option(pta.rendering_device.PTK_OPT_LAUNCH_TIMING, 1)
     cnt = dict(zip(pta.rendering_device.COUNTER_NAMES, counters.tolist()))
     rays_local = cnt["rays"]
 

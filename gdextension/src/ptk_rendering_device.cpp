@@ -312,6 +312,7 @@ void PtkRenderingDevice::_bind_methods() {
     BIND_CONSTANT(PTK_DISPLAY_CANVAS_SRGB);
     BIND_CONSTANT(PTK_REFIT_MESH);
     BIND_CONSTANT(PTK_OPT_TRIANGLE_UVS);
+    BIND_CONSTANT(PTK_OPT_LAUNCH_TIMING);
     BIND_CONSTANT(PTK_BVH_SAH);
     BIND_CONSTANT(PTK_RENDERER_AUTO);
     BIND_CONSTANT(PTK_RENDERER_SINGLE_KERNEL);

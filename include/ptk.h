@@ -203,8 +203,11 @@ int ptk_mesh_to_triangles(ptk_ctx* ctx, const ptk_mesh_surface* surface, const f
  * (ray_tracer.comp:396-406) -- is read as six floats per triangle record, the (u,v) of point1, point2, point3
  * (ptk_mesh_to_triangles' uvs6), and a triangle hit's uv becomes their interpolation
  * (1-u-v)*uv1 + u*uv2 + v*uv3 instead of the barycentric (u,v) themselves: the conversion the shader leaves as
- * a TODO at ray_tracer.comp:1071-1072.  Triangles past the end of the table keep the barycentric uv. */
-enum { PTK_OPT_TRIANGLE_UVS = 1 };
+ * a TODO at ray_tracer.comp:1071-1072.  Triangles past the end of the table keep the barycentric uv.
+ * PTK_OPT_LAUNCH_TIMING (default 0): with 1, the WAVEFRONT pipeline records a HIP event before and after each
+ * of its traversal launches, which ptk_dispatch_traverse_ms reads; each record costs about 3 us of stream time,
+ * so it is off unless somebody measures. */
+enum { PTK_OPT_TRIANGLE_UVS = 1, PTK_OPT_LAUNCH_TIMING = 2 };
 int ptk_set_option(ptk_ctx* ctx, int option, int value);
 
 /* Measurement hooks.  The reference counts box and object tests per invocation
@@ -243,7 +246,8 @@ enum { PTK_RENDERER_AUTO = 0, PTK_RENDERER_SINGLE_KERNEL = 1, PTK_RENDERER_WAVEF
 int ptk_set_renderer(ptk_ctx* ctx, int renderer);
 /* Durations (ms) of the traversal-kernel launches of the dispatch `back` calls ago (0 = the last
  * one), from HIP events on the context's stream.  *n_launches = number of launches (0 when that
- * dispatch used the one-kernel renderer); ms needs room for that many. */
+ * dispatch used another renderer); ms needs room for that many.  A dispatch issued with
+ * PTK_OPT_LAUNCH_TIMING off has no events: its durations read -1. */
 int ptk_dispatch_traverse_ms(ptk_ctx* ctx, int back, float* ms, int capacity, int* n_launches);
 
 /* How often the library had to re-validate the bound scene and rebuild its derived structures

@@ -68,6 +68,7 @@ struct ptk_ctx {
     // configuration (ptk_configure)
     int order = 8, refraction_mode = 2, use_emission = 0, early_t_break = 0;
     int opt_triangle_uvs = 0;  // PTK_OPT_TRIANGLE_UVS
+    int opt_launch_timing = 0; // PTK_OPT_LAUNCH_TIMING
     int n_proc = 0;
     int proc_builtin[PTK_MAX_PROC] = {0};
     // derived state, rebuilt when a bound buffer changes
@@ -143,6 +144,7 @@ struct ptk_ctx {
     uint32_t n_top = 0;            // blocks [0, n_top): top of the tree, breadth-first, LDS-resident in the traversal kernel
     hipEvent_t* wf_ev[kTimingRing] = {nullptr};  // per dispatch slot: 2 events per traversal launch
     int wf_iters[kTimingRing] = {0};            // traversal launches of that dispatch (0: one-kernel renderer)
+    bool wf_timed[kTimingRing] = {false};       // ... and whether the events were recorded around them
     // tracing
     int trace_flags = 0;
     int* d_trace_primary = nullptr;
@@ -1311,13 +1313,14 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         P.wf.carry_cap = (uint32_t)cap;
         n_launches = n_iter + ctx->wf_max_lag;  // a parked path runs at most this many launches behind its bounce number
     }
-    if (!ctx->wf_ev[slot]) {
+    if (ctx->opt_launch_timing && !ctx->wf_ev[slot]) {
         ctx->wf_ev[slot] = new hipEvent_t[2 * PTK_WF_MAX_ITER];
         for (int k = 0; k < 2 * PTK_WF_MAX_ITER; k++) HIP_TRY(ctx, hipEventCreate(&ctx->wf_ev[slot][k]));
     }
     ctx->wf_iters[slot] = n_launches;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
-    HIP_TRY(ctx, ptk_launch_wavefront(&P, groups_x, groups_y, n_launches, wf_lds, n_wgs, ctx->wf_ev[slot], ctx->stream));
+    ctx->wf_timed[slot] = ctx->opt_launch_timing != 0;
+    HIP_TRY(ctx, ptk_launch_wavefront(&P, groups_x, groups_y, n_launches, wf_lds, n_wgs, ctx->wf_timed[slot] ? ctx->wf_ev[slot] : nullptr, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
     ctx->dispatch_count++;
     return PTK_OK;
@@ -1410,6 +1413,7 @@ int ptk_update_stats(ptk_ctx* ctx, long long* full_validations, long long* patch
 int ptk_set_option(ptk_ctx* ctx, int option, int value) {
     if (!ctx) return PTK_E_INVALID;
     if (option == PTK_OPT_TRIANGLE_UVS) { ctx->opt_triangle_uvs = value ? 1 : 0; return PTK_OK; }
+    if (option == PTK_OPT_LAUNCH_TIMING) { ctx->opt_launch_timing = value ? 1 : 0; return PTK_OK; }
     return fail(ctx, PTK_E_INVALID, "unknown option %d", option);
 }
 
@@ -1431,6 +1435,7 @@ int ptk_dispatch_traverse_ms(ptk_ctx* ctx, int back, float* ms, int capacity, in
     *n_launches = n;
     if (n > 0 && (!ms || capacity < n)) return fail(ctx, PTK_E_INVALID, "room for %d durations needed", n);
     for (int k = 0; k < n; k++) {
+        if (!ctx->wf_timed[slot]) { ms[k] = -1.0f; continue; }
         HIP_TRY(ctx, hipEventSynchronize(ctx->wf_ev[slot][2 * k + 1]));
         HIP_TRY(ctx, hipEventElapsedTime(&ms[k], ctx->wf_ev[slot][2 * k], ctx->wf_ev[slot][2 * k + 1]));
     }

@@ -38,6 +38,7 @@ EXPORTS = [
 PTK_RENDERER_AUTO, PTK_RENDERER_SINGLE_KERNEL, PTK_RENDERER_WAVEFRONT, PTK_RENDERER_PERSISTENT = 0, 1, 2, 3
 
 PTK_REFIT_MESH = 4
+PTK_OPT_TRIANGLE_UVS, PTK_OPT_LAUNCH_TIMING = 1, 2
 
 
 class PtkRefitEvent(C.Structure):
@@ -389,7 +390,8 @@ class PtkRenderingDevice:
         self._check(self.lib.ptk_comm_destroy(self.ctx), "ptk_comm_destroy")
 
     def set_option(self, option: int, value: int):
-        """PTK_OPT_* switches (1 = PTK_OPT_TRIANGLE_UVS: interpolate the corner UVs bound at (4,1))."""
+        """PTK_OPT_* switches (PTK_OPT_TRIANGLE_UVS: interpolate the corner UVs bound at (4,1); PTK_OPT_LAUNCH_TIMING:
+        events around the pipeline's traversal launches, for dispatch_traverse_ms)."""
         self._check(self.lib.ptk_set_option(self.ctx, int(option), int(value)), "ptk_set_option")
 
     def set_renderer(self, renderer: int):
@@ -397,7 +399,8 @@ class PtkRenderingDevice:
         self._check(self.lib.ptk_set_renderer(self.ctx, int(renderer)), "ptk_set_renderer")
 
     def dispatch_traverse_ms(self, back: int = 0):
-        """Durations of the traversal-kernel launches of the dispatch `back` calls ago ([] = one-kernel renderer)."""
+        """Durations of the traversal-kernel launches of the dispatch `back` calls ago ([] = another renderer ran;
+        -1 each when PTK_OPT_LAUNCH_TIMING was off)."""
         arr = (C.c_float * 64)()
         n = C.c_int(0)
         self._check(self.lib.ptk_dispatch_traverse_ms(self.ctx, back, arr, 64, C.byref(n)), "ptk_dispatch_traverse_ms")

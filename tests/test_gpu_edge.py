@@ -138,7 +138,15 @@ def test_wavefront_hands_over_outside_its_range(pta, rd, golden_dir):
         ob.render(packed, wd.push_constant_bytes(scene.camera, win, wd.sample_time(1)), cpu, w // 8, h // 8)
         d.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
         assert len(dev.dispatch_traverse_ms(0)) > 40
+        assert all(t == -1.0 for t in dev.dispatch_traverse_ms(0)), "launch timing is off unless asked for"
         _compare_image("depth40 pipeline", dev.texture_get_data(d.image_buffer), cpu)
+        # the same dispatch with events around its traversal launches: same image, durations reported
+        dev.set_option(pta.rendering_device.PTK_OPT_LAUNCH_TIMING, 1)
+        dev.texture_update(d.image_buffer, np.zeros((h, w, 4), np.float32))
+        d.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
+        timed = dev.dispatch_traverse_ms(0)
+        assert len(timed) > 40 and all(t > 0.0 for t in timed)
+        _compare_image("depth40 pipeline, timed", dev.texture_get_data(d.image_buffer), cpu)
         d.free_rids()
     finally:
         dev.close()

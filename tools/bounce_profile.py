@@ -13,6 +13,7 @@ disp.set_scene(scene)
 disp.create_buffers(1920, 1080, order=8)
 disp.load_shader()
 rd.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
+rd.set_option(pta.rendering_device.PTK_OPT_LAUNCH_TIMING, 1)
 win = wd.PTRenderWindow(render_width=1920, render_height=1080, max_ray_depth=8, max_refraction_bounces=4)
 acc = None
 n = 10

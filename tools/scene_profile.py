@@ -20,6 +20,7 @@ disp.set_scene(scene)
 disp.create_buffers(w, h, order=8)
 disp.load_shader(refraction_mode=2, use_emission=(name == "fake_cornell_box"), early_t_break=False)
 rd.set_renderer(renderer)
+rd.set_option(pta.rendering_device.PTK_OPT_LAUNCH_TIMING, 1)
 win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=depth, max_refraction_bounces=bounces)
 n = 20
 for k in range(n + 2):

@@ -15,6 +15,7 @@ else:  # a fixture scene by name, e.g. benchmark_random_scene, dragon_test, fake
     scene = pta.scenes.load_fixture_scene(which, os.path.join(ROOT, "tests", "golden"))
 rd = pta.PtkRenderingDevice(0)
 rd.set_renderer(int(os.environ.get("PTK_RENDERER", "0")))
+rd.set_option(pta.rendering_device.PTK_OPT_LAUNCH_TIMING, 1)
 disp = wd.PTWorkDispatcher(rd)
 disp.set_scene(scene)
 bvh_type = int(os.environ["PTK_BVH_TYPE"]) if os.environ.get("PTK_BVH_TYPE") else None  # 5 = binned SAH
