@@ -1,0 +1,36 @@
+"""profiles/traffic.json from a counter summary of tools/pmc_passes.sh (development aid).
+usage: python tools/traffic_from_pmc.py gpurun_out/pmc_<tag>.json profiles/round2/<tag>_pmc_traverse.json
+Memory-side bytes per launch of the traversal kernel (FETCH_SIZE doubled, the gfx950 correction for 16-byte-per-lane
+loads, plus WRITE_SIZE, both in KiB-like units of 1024 bytes), the L2 hit rate, and how busy the units were that bound
+the kernel: busy cycles summed over the 256 compute units against the launch's cycles (GRBM_GUI_ACTIVE is summed
+over the 8 XCDs)."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, kept_as = sys.argv[1], sys.argv[2]
+r = json.load(open(src))
+m = lambda g, k: r[g][k]["mean_per_dispatch"]
+cycles = m("B", "GRBM_GUI_ACTIVE") / 8.0
+n_cu = 256
+fetch_kb, write_kb = m("F", "FETCH_SIZE"), m("W", "WRITE_SIZE")
+old = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+out = {
+    "workload": old["workload"],
+    "kernel": "ptk_wf_traverse",
+    "command": old["command"],
+    "launches_averaged": r["F"]["FETCH_SIZE"]["dispatches"],
+    "fetch_size_kb_per_launch": fetch_kb,
+    "write_size_kb_per_launch": write_kb,
+    "correction": old["correction"],
+    "traverse_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
+    "l2_hit_rate": m("W", "TCC_HIT_sum") / (m("W", "TCC_HIT_sum") + m("W", "TCC_MISS_sum")),
+    "limiter": {
+        "what": old["limiter"]["what"],
+        "valu_busy": m("A", "SQ_ACTIVE_INST_VALU") / (cycles * n_cu),
+        "ta_busy": m("B", "TA_TA_BUSY_sum") / (cycles * n_cu),
+        "td_busy": m("B", "TD_TD_BUSY_sum") / (cycles * n_cu),
+        "cycles_per_launch": cycles,
+        "source": kept_as,
+    },
+}
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
