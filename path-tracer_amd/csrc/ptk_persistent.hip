@@ -182,7 +182,7 @@ __global__ __launch_bounds__(PTK_PP_MAX_WG_WAVES * 64) void ptk_path_kernel(cons
         if (PTK_VOTE_INNER(__popcll(mi), __popcll(ml))) {
             if (is_inner) pop = trav_inner(P, S, T);
         } else {
-            trav_leaf(P, T, is_leaf);
+            trav_leaf(P, S, T, is_leaf);
             pop = is_leaf;
         }
         if (pop) {

@@ -133,7 +133,9 @@ PTK_DEV float hit_aabb(float4 bmin, float4 bmax, f3 o, f3 inv, int neg_mask, flo
 }
 
 // Ray-sphere test on a sphere given by value (:803-841).
-PTK_DEV void hit_sphere_rec(Ray& ray, Hit& h, int object_id, int cur_xf, f3 center, float radius) {
+// `either_root` (optional): set when the first root is taken although the second lies in the range too and is
+// the smaller one -- the one case in which a smaller ray.end could have led to the other root (see trav_leaf).
+PTK_DEV void hit_sphere_rec(Ray& ray, Hit& h, int object_id, int cur_xf, f3 center, float radius, bool* either_root = nullptr) {
     f3 oc = ray.o - center;
     float half_b = dot3(-oc, ray.d);
     float r_sqrd = radius * radius;
@@ -147,6 +149,8 @@ PTK_DEV void hit_sphere_rec(Ray& ray, Hit& h, int object_id, int cur_xf, f3 cent
     if (!in_range(root, ray.start, ray.end)) {
         root = q;
         if (!in_range(root, ray.start, ray.end)) return;
+    } else if (either_root && q < root && in_range(q, ray.start, ray.end)) {
+        *either_root = true;
     }
     h.hit = 1; h.object_id = object_id; h.transform_index = cur_xf;
     ray.end = root;
@@ -811,30 +815,105 @@ PTK_DEV bool trav_inner(const PtkParams& P, const Stack& S, Trav& T) {
     return added == 0;
 }
 
-// One leaf round for the whole wave: lanes with is_leaf test their leaf's objects in order (:1137-1142);
-// the loop runs to the largest leaf among them.  Leaf records: {A.xyz | centre.xyz, object id},
+// Objects [first, first + count) of a leaf against ray r, in order (:1137-1142), for every lane of the wave with
+// its own span; the loop runs to the longest span among them.  Leaf records: {A.xyz | centre.xyz, object id},
 // {B.xyz | radius, -}, {C.xyz, -}, stored in object-id-slot order.
-PTK_DEV void trav_leaf(const PtkParams& P, Trav& T, bool is_leaf) {
-    int node_size = 0, base = 0;
-    if (is_leaf) {
-        node_size = iabs(bfe_i((int)T.cur, 24, 8));
-        base = iabs(bfe_i((int)T.cur, 0, 24)) - 1;
-    }
-    const float4* __restrict__ rec = P.wf.leaf_records + (size_t)base * 3;
-    Ray r;
-    r.o = T.o; r.d = T.d; r.start = T.start; r.end = T.end;
+PTK_DEV void leaf_span(const PtkParams& P, int first, int count, int cur_xf, Ray& r, Hit& h, bool* either_root) {
+    const float4* __restrict__ rec = P.wf.leaf_records + (size_t)first * 3;
     for (int k = 0;; k++) {
-        const bool go = k < node_size;
+        const bool go = k < count;
         if (__ballot(go) == 0ull) break;
         if (go) {
             const float4 r0 = rec[k * 3], r1 = rec[k * 3 + 1], r2 = rec[k * 3 + 2];
             const int object_id = (int)fbits(r0.w);
             const int type = bfe_i(object_id, 24, 8);
-            if (type == IS_TRIANGLE) hit_triangle_rec(r, T.h, object_id, T.cur_xf, ld3(r0), ld3(r1), ld3(r2));
-            else if (type == IS_SPHERE) hit_sphere_rec(r, T.h, object_id, T.cur_xf, ld3(r0), r1.x);
+            if (type == IS_TRIANGLE) hit_triangle_rec(r, h, object_id, cur_xf, ld3(r0), ld3(r1), ld3(r2));
+            else if (type == IS_SPHERE) hit_sphere_rec(r, h, object_id, cur_xf, ld3(r0), r1.x, either_root);
         }
     }
-    T.end = r.end;
+}
+
+PTK_DEV int wave_rank_in(unsigned long long mask) {  // set bits of mask below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+PTK_DEV float lane_read_f(int src_lane, float v) { return bitsf((uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)fbits(v))); }
+PTK_DEV int lane_read_i(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+
+// One leaf round for the whole wave: lanes with is_leaf test their leaf's objects.
+//
+// The lanes that are not at a leaf help: a leaf of more than PTK_LEAF_SPLIT objects is split in two, the owner
+// takes the first half and a helper lane, with a copy of the owner's ray, the second, so the round lasts half as
+// many tests (leaves hold up to eight objects, 4.3 on average on the 262 144-triangle scene, and the loop runs
+// to the longest).  The result is the shader's: every test accepts a hit iff its distance t lies in
+// [ray.start, ray.end] and then sets ray.end = t, so the objects in order leave the smallest t, the last one
+// among equals, whatever ray.end the later ones saw on the way; the helper's half starts from the ray.end of the
+// leaf's start, and its hit replaces the owner's iff its t <= the owner's final ray.end.  A test's t itself
+// depends on ray.end in one corner only -- a sphere whose second root is the smaller one and lies in the range as
+// well (hit_sphere_rec's either_root) -- and a helper that meets it hands the whole leaf back to its owner.
+// The spare row of the wave's stack window is where owners and helpers find each other.
+#ifndef PTK_LEAF_SPLIT
+#define PTK_LEAF_SPLIT 4
+#endif
+PTK_DEV void trav_leaf(const PtkParams& P, const Stack& S, Trav& T, bool is_leaf) {
+    int n = 0, base = 0;
+    if (is_leaf) {
+        n = iabs(bfe_i((int)T.cur, 24, 8));
+        base = iabs(bfe_i((int)T.cur, 0, 24)) - 1;
+    }
+    Ray r;
+    r.o = T.o; r.d = T.d; r.start = T.start; r.end = T.end;
+    const bool big = n > PTK_LEAF_SPLIT;
+    const unsigned long long m_big = __ballot(big), m_free = __ballot(!is_leaf);
+    if (m_big == 0ull || m_free == 0ull) {  // nothing to split, or nobody to help
+        leaf_span(P, base, n, T.cur_xf, r, T.h, nullptr);
+        T.end = r.end;
+        return;
+    }
+    int* const spare = S.lds + S.lds_cap * 64;
+    const int n_big = __popcll(m_big), n_free = __popcll(m_free);
+    const int n_pairs = n_big < n_free ? n_big : n_free;
+    const int r_big = wave_rank_in(m_big), r_free = wave_rank_in(m_free);
+    const bool helped = big && r_big < n_pairs, helper = !is_leaf && r_free < n_pairs;
+    if (helped) spare[r_big] = S.lane;                    // the r-th owner ...
+    __builtin_amdgcn_wave_barrier();
+    int partner = S.lane;
+    if (helper) partner = spare[r_free];                  // ... and the r-th free lane are a pair
+    __builtin_amdgcn_wave_barrier();
+    if (helper) spare[partner] = S.lane;                  // (the owner learns its helper's lane)
+    // the helper's copy of its owner's ray and leaf (every lane reads: its own values, or its partner's)
+    r.o = mk3(lane_read_f(partner, r.o.x), lane_read_f(partner, r.o.y), lane_read_f(partner, r.o.z));
+    r.d = mk3(lane_read_f(partner, r.d.x), lane_read_f(partner, r.d.y), lane_read_f(partner, r.d.z));
+    r.start = lane_read_f(partner, r.start);
+    r.end = lane_read_f(partner, r.end);
+    const int pn = lane_read_i(partner, n), pbase = lane_read_i(partner, base);
+    const int half = (pn + 1) >> 1;
+    int first = base, count = n;
+    if (helped) count = half;
+    if (helper) { first = pbase + half; count = pn - half; }
+    Hit h = T.h;
+    if (helper) { h.hit = 0; h.object_id = 0; h.transform_index = -1; h.u = 0.0f; h.v = 0.0f; }
+    bool either_root = false;
+    leaf_span(P, first, count, T.cur_xf, r, h, helper ? &either_root : nullptr);
+    __builtin_amdgcn_wave_barrier();
+    int from = S.lane;
+    if (helped) from = spare[S.lane];
+    // the owner takes its helper's hit if that one is at least as near (it is the later one in the leaf's order)
+    const int o_hit = lane_read_i(from, h.hit), o_id = lane_read_i(from, h.object_id);
+    const float o_u = lane_read_f(from, h.u), o_v = lane_read_f(from, h.v), o_end = lane_read_f(from, r.end);
+    const bool o_redo = lane_read_i(from, either_root ? 1 : 0) != 0;
+    if (helped && o_hit && o_end <= r.end) {
+        h.hit = 1; h.object_id = o_id; h.transform_index = T.cur_xf; h.u = o_u; h.v = o_v;
+        r.end = o_end;
+    }
+    const bool redo = helped && o_redo;
+    if (__ballot(redo) != 0ull) {  // (the sphere corner: these owners run their whole leaf alone)
+        Ray r2;
+        r2.o = T.o; r2.d = T.d; r2.start = T.start; r2.end = T.end;
+        Hit h2 = T.h;
+        leaf_span(P, base, redo ? n : 0, T.cur_xf, r2, h2, nullptr);
+        if (redo) { h = h2; r.end = r2.end; }
+    }
+    if (is_leaf) { T.h = h; T.end = r.end; }
 }
 
 // Next node of the lane: pop; an empty mesh sub-stack first maps the ray back to world space (:1309-1310).
@@ -863,7 +942,7 @@ PTK_DEV Hit check_ray_hit_blocks(const PtkParams& P, Ray& ray, const Stack& S) {
         if (PTK_VOTE_INNER(__popcll(mi), __popcll(ml))) {
             if (is_inner) pop = trav_inner(P, S, T);
         } else {
-            trav_leaf(P, T, is_leaf);
+            trav_leaf(P, S, T, is_leaf);
             pop = is_leaf;
         }
         if (pop) trav_pop(S, T);

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
         if (PTK_WF_VOTE_INNER(__popcll(mi), __popcll(ml))) {
             if (is_inner) pop = trav_inner(P, S, T);  // ---- inner round ----
         } else {
-            trav_leaf(P, T, is_leaf);                 // ---- leaf round ----
+            trav_leaf(P, S, T, is_leaf);                 // ---- leaf round ----
             pop = is_leaf;
         }
         if (pop) trav_pop(S, T);
