@@ -90,6 +90,7 @@ struct ptk_ctx {
     float root_box[6] = {0};
     uint32_t root_entry = 0;
     uint32_t n_blocks = 0, n_sockets = 0, n_records = 0;
+    bool leaves_hold_triangles = false;  // any triangle in the id table (decides whether long leaves are split, see trav_leaf)
     // host mirrors and maps of the derived structures, for patching them on buffer_update
     std::vector<float> h_blocks, h_leaf_records;
     std::vector<int32_t> h_sockets;  // {entry of the mesh's root, transform index} per world-level socket
@@ -919,6 +920,7 @@ static int validate_scene(ptk_ctx* ctx) {
     leaf_records.assign((size_t)std::max(n_ids, 1) * 12, 0.0f);
     ctx->tri_slot.assign((size_t)n_tri, -1);
     ctx->sph_slot.assign((size_t)n_sph, -1);
+    ctx->leaves_hold_triangles = false;
     for (int i = 0; i < n_ids; i++) {
         const int oid = idp[i];
         const int type = sext(oid, 24, 8), oi = sext(oid, 0, 24);
@@ -927,6 +929,7 @@ static int validate_scene(ptk_ctx* ctx) {
             const uint8_t* t = tri->shadow.data() + (size_t)oi * 80;
             memcpy(r + 0, t + 0, 12); memcpy(r + 4, t + 16, 12); memcpy(r + 8, t + 32, 12);
             memcpy(r + 3, &oid, 4);
+            ctx->leaves_hold_triangles = true;
             ctx->tri_slot[oi] = ctx->tri_slot[oi] == -1 ? i : -2;  // -2: listed more than once
         } else if (type == 1 && oi >= 0 && oi < n_sph) {
             const uint8_t* sp = sph->shadow.data() + (size_t)oi * 32;
@@ -1071,6 +1074,8 @@ static void fill_blocks(const ptk_ctx* ctx, PtkParams& P) {
     P.wf.n_chain = ctx->n_chain;
     memcpy(P.wf.chain, ctx->chain, sizeof P.wf.chain);
     P.wf.n_blocks = ctx->n_blocks; P.wf.n_sockets = ctx->n_sockets; P.wf.n_records = ctx->n_records;
+    // leaves longer than this are shared with a helper lane: worth its set-up for triangle tests, not for sphere tests
+    P.wf.leaf_split = ctx->leaves_hold_triangles ? 4 : 255;
     P.wf.leaf_records = ctx->d_leaf_records;
 }
 

@@ -841,7 +841,8 @@ PTK_DEV int lane_read_i(int src_lane, int v) { return __builtin_amdgcn_ds_bpermu
 
 // One leaf round for the whole wave: lanes with is_leaf test their leaf's objects.
 //
-// The lanes that are not at a leaf help: a leaf of more than PTK_LEAF_SPLIT objects is split in two, the owner
+// The lanes that are not at a leaf help: a leaf of more than PtkWavefront::leaf_split objects (4 where there are
+// triangles: measured 2..5; never in scenes of spheres only, whose tests are too short for it) is split in two, the owner
 // takes the first half and a helper lane, with a copy of the owner's ray, the second, so the round lasts half as
 // many tests (leaves hold up to eight objects, 4.3 on average on the 262 144-triangle scene, and the loop runs
 // to the longest).  The result is the shader's: every test accepts a hit iff its distance t lies in
@@ -851,9 +852,6 @@ PTK_DEV int lane_read_i(int src_lane, int v) { return __builtin_amdgcn_ds_bpermu
 // depends on ray.end in one corner only -- a sphere whose second root is the smaller one and lies in the range as
 // well (hit_sphere_rec's either_root) -- and a helper that meets it hands the whole leaf back to its owner.
 // The spare row of the wave's stack window is where owners and helpers find each other.
-#ifndef PTK_LEAF_SPLIT
-#define PTK_LEAF_SPLIT 4
-#endif
 PTK_DEV void trav_leaf(const PtkParams& P, const Stack& S, Trav& T, bool is_leaf) {
     int n = 0, base = 0;
     if (is_leaf) {
@@ -862,7 +860,7 @@ PTK_DEV void trav_leaf(const PtkParams& P, const Stack& S, Trav& T, bool is_leaf
     }
     Ray r;
     r.o = T.o; r.d = T.d; r.start = T.start; r.end = T.end;
-    const bool big = n > PTK_LEAF_SPLIT;
+    const bool big = n > P.wf.leaf_split;
     const unsigned long long m_big = __ballot(big), m_free = __ballot(!is_leaf);
     if (m_big == 0ull || m_free == 0ull) {  // nothing to split, or nobody to help
         leaf_span(P, base, n, T.cur_xf, r, T.h, nullptr);
