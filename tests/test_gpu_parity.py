@@ -163,6 +163,20 @@ def test_random_spheres_10k(pta, rd, rd_wf, golden_dir):
     _run_case(pta, rd, rd_wf, golden_dir, "spheres10k", 320, 184, 8, 4, dispatches=2, scene=scene)
 
 
+def test_spheres_and_triangles_share_leaves(pta, rd, rd_wf, golden_dir):
+    """Leaves of up to eight objects that mix spheres and triangles: with triangles in the scene, long leaves
+    are shared between a lane and a helper lane, so sphere tests run on helpers too."""
+    scene = pta.scenes.random_spheres_scene(grid=14, seed=11)
+    rng = np.random.default_rng(5)
+    mat = scene.spheres[0].material
+    for _ in range(300):
+        c = rng.uniform(-12.0, 12.0, 3).astype(np.float32)
+        c[1] = abs(c[1]) * 0.15 + 0.2
+        a, b = rng.uniform(-0.6, 0.6, (2, 3)).astype(np.float32)
+        scene.add_object(pta.scene.PTTriangle(material=mat, vertex1=tuple(c), vertex2=tuple(c + a), vertex3=tuple(c + b)))
+    _run_case(pta, rd, rd_wf, golden_dir, "spheres+triangles", 320, 184, 6, 4, dispatches=2, scene=scene)
+
+
 # ---- size-independent properties at full BASELINE sizes ------------------------------------------
 @pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
 def test_full_size_tiles_equal_whole(pta, rd, rd_wf, golden_dir, w, h):
