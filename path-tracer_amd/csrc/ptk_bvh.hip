@@ -218,6 +218,17 @@ __global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls,
         bool fast = false;
         float mx = mine.p[0], my = mine.p[1], mz = mine.p[2];
         if (j0 == 0 && vmask == ~0ull) {
+            // A batch that moves neither end of the box -- every element's position strictly above the box's and
+            // its far end strictly below the box's, on all three axes -- leaves p as it is and turns s into
+            // (p + s) - p at every step: nothing at all if s is that already.  In a long unordered list almost
+            // every batch is of this kind (the running extremes of n elements change about ln n times).
+            {
+                const float e1x = px + sx, e1y = py + sy, e1z = pz + sz;
+                const bool inside = mx > px && my > py && mz > pz && e2x < e1x && e2y < e1y && e2z < e1z;
+                const bool settled = __float_as_uint(e1x - px) == __float_as_uint(sx) && __float_as_uint(e1y - py) == __float_as_uint(sy) &&
+                                     __float_as_uint(e1z - pz) == __float_as_uint(sz);
+                if (settled && __all(inside)) continue;
+            }
             // A full batch of valid boxes.  The position after element j is the running "p < bp ? p : bp" over the
             // elements up to j, an associative pick (smallest value, the later one among equals) that does not
             // depend on the sizes: all 64 are found at once by a scan.
