@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstring>
 #include <initializer_list>
+#include <mutex>
 
 #include "ptk_bvh.h"
 
@@ -977,18 +978,77 @@ __global__ __launch_bounds__(64) void k_sah_round(const SahSet* sets, int n_sets
 }
 
 // ---- host side -------------------------------------------------------------------------------------------
+// Device allocations of the builder come from a small cache: hipMalloc and hipFree cost 50-200 us each (hipFree
+// waits for the device besides), and a build makes some thirty of them, which was a third of a large build's wall
+// time and most of a small one's.  Freed blocks are kept by size class (powers of two from 4 KiB) and device, up
+// to kPoolBytes per device; ptk_bvh_pool_trim gives them back.
+namespace pool {
+constexpr size_t kPoolBytes = (size_t)1 << 30;
+struct Free { void* p; size_t bytes; int device; unsigned long long stamp; };
+std::mutex g_mutex;
+std::vector<Free> g_free;
+size_t g_held[64] = {0};
+// A block may come back while work that uses it is still queued (an error path, a handle freed right after a call):
+// every return is stamped, and a block is handed out again only after one device-wide wait that is later than its
+// return (one wait covers everything returned before it, so a build costs at most one).
+unsigned long long g_stamp = 0, g_waited_upto = 0;
+size_t size_class(size_t bytes) {
+    size_t c = 4096;
+    while (c < bytes) c <<= 1;
+    return c;
+}
+void* take(size_t bytes, size_t* got) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    const size_t c = size_class(bytes);
+    *got = c;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        for (size_t i = 0; i < g_free.size(); i++)
+            if (g_free[i].device == dev && g_free[i].bytes == c) {
+                void* p = g_free[i].p;
+                if (g_free[i].stamp > g_waited_upto) {
+                    const unsigned long long now = g_stamp;
+                    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+                    g_waited_upto = now;
+                }
+                g_free[i] = g_free.back();
+                g_free.pop_back();
+                if (dev >= 0 && dev < 64) g_held[dev] -= c;
+                return p;
+            }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, c) != hipSuccess) return nullptr;
+    return p;
+}
+void give(void* p, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (g_held[dev] + bytes <= kPoolBytes) {
+            g_free.push_back({p, bytes, dev, ++g_stamp});
+            g_held[dev] += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+}  // namespace pool
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    size_t cap = 0;
+    size_t cap = 0, bytes = 0;
+    ~DevBuf() { if (p) pool::give(p, bytes); }
     bool alloc(size_t count) {  // contents are not kept; an allocation that is large enough is reused
         n = count;
         if (p && cap >= std::max<size_t>(count, 1)) return true;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        cap = std::max<size_t>(count, 1);
-        if (hipMalloc((void**)&p, cap * sizeof(T)) != hipSuccess) { p = nullptr; cap = 0; return false; }
+        if (p) { pool::give(p, bytes); p = nullptr; cap = 0; bytes = 0; }
+        p = (T*)pool::take(std::max<size_t>(count, 1) * sizeof(T), &bytes);
+        if (!p) { cap = 0; bytes = 0; return false; }
+        cap = bytes / sizeof(T);
         return true;
     }
 };
@@ -1275,20 +1335,24 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
 
             // host: one new node per non-empty bin, in bin order (:327-371)
             std::vector<PendingCall> next;
-            std::vector<int> fix_begin, fix_end;  // terminal bins of lists with sockets: need objects/sockets split
+            next.reserve((size_t)nc * 4);
+            T.nodes.reserve(T.nodes.size() + (size_t)nc * T.order);
             for (int i = 0; i < nc; i++) {
                 const int n = calls[i].end - calls[i].begin;
-                std::vector<std::pair<int, int>> ranges;  // [begin,end) of each bin list, in order
+                std::pair<int, int> ranges[MAXB];  // [begin,end) of each bin list, in order
+                int n_ranges = 0;
                 if (mv[i]) {
                     int run = calls[i].begin;
-                    for (int b = 0; b < segc[i]; b++) { ranges.push_back({run, run + ho[i].counts[b]}); run += ho[i].counts[b]; }
+                    for (int b = 0; b < segc[i]; b++) { ranges[n_ranges++] = {run, run + ho[i].counts[b]}; run += ho[i].counts[b]; }
                 } else {
                     int half = n / 2;  // a single occupied bin is cut in halves
-                    ranges.push_back({calls[i].begin, calls[i].begin + half});
-                    ranges.push_back({calls[i].begin + half, calls[i].end});
+                    ranges[n_ranges++] = {calls[i].begin, calls[i].begin + half};
+                    ranges[n_ranges++] = {calls[i].begin + half, calls[i].end};
                 }
                 const int mesh_count = ho[i].mesh_count;
-                for (auto& r : ranges) {
+                T.nodes[calls[i].parent].children.reserve(n_ranges);
+                for (int q = 0; q < n_ranges; q++) {
+                    const std::pair<int, int>& r = ranges[q];
                     int cnt = r.second - r.first;
                     if (cnt == 0) continue;
                     int id = (int)T.nodes.size();
@@ -1382,7 +1446,9 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
     CK(hipMemsetAsync(T.node_aabb.p, 0, sizeof(float) * 6 * nn, st));
     {
         // depth of every node, then inner nodes deepest first
-        std::vector<int> depth(nn, 0), order_bfs = {0};
+        std::vector<int> depth(nn, 0), order_bfs;
+        order_bfs.reserve(nn);
+        order_bfs.push_back(0);
         int maxd = 0;
         for (size_t q = 0; q < order_bfs.size(); q++) {
             int x = order_bfs[q];
@@ -1391,19 +1457,35 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
         // one upload: [leaf node | first object | object count] per leaf, then [node | first child slot | child count]
         // per inner node grouped by depth (deepest first), then the child lists
         std::vector<int> ln, ob, oc;
-        for (int i = 0; i < nn; i++) if (T.nodes[i].kind == N_LEAF) { ln.push_back(i); ob.push_back(T.nodes[i].obj_begin); oc.push_back(T.nodes[i].obj_count); }
+        ln.reserve(nn); ob.reserve(nn); oc.reserve(nn);
+        std::vector<int> per_depth(maxd + 2, 0);  // inner nodes of each depth
+        size_t n_child_slots = 0;
+        for (int i = 0; i < nn; i++) {
+            if (T.nodes[i].kind == N_LEAF) { ln.push_back(i); ob.push_back(T.nodes[i].obj_begin); oc.push_back(T.nodes[i].obj_count); }
+            else if (T.nodes[i].kind == N_INNER) { per_depth[depth[i]]++; n_child_slots += T.nodes[i].children.size(); }
+        }
         const int nl = (int)ln.size();
-        std::vector<std::vector<int>> by_depth(maxd + 1);
-        for (int i = 0; i < nn; i++) if (T.nodes[i].kind == N_INNER && (i == 0 || depth[i] > 0)) by_depth[depth[i]].push_back(i);
-        std::vector<int> nd, cb, cc, ch, group_first, group_count;
-        for (int d = maxd; d >= 0; d--) {
-            if (by_depth[d].empty()) continue;
-            group_first.push_back((int)nd.size());
-            group_count.push_back((int)by_depth[d].size());
-            for (int i : by_depth[d]) {
-                nd.push_back(i); cb.push_back((int)ch.size()); cc.push_back((int)T.nodes[i].children.size());
-                for (int c : T.nodes[i].children) ch.push_back(c);
+        std::vector<int> group_first, group_count, place(maxd + 2, 0);
+        {
+            int at = 0;
+            for (int d = maxd; d >= 0; d--) {
+                place[d] = at;
+                if (per_depth[d] == 0) continue;
+                group_first.push_back(at);
+                group_count.push_back(per_depth[d]);
+                at += per_depth[d];
             }
+        }
+        int n_inner = 0;
+        for (int d = 0; d <= maxd; d++) n_inner += per_depth[d];
+        std::vector<int> nd(n_inner), cb(n_inner), cc(n_inner), ch;
+        for (int i = 0; i < nn; i++) if (T.nodes[i].kind == N_INNER) nd[place[depth[i]]++] = i;  // (ascending node index within a depth)
+        ch.reserve(n_child_slots);
+        for (int k = 0; k < n_inner; k++) {
+            const HNode& x = T.nodes[nd[k]];
+            cb[k] = (int)ch.size();
+            cc[k] = (int)x.children.size();
+            ch.insert(ch.end(), x.children.begin(), x.children.end());
         }
         const int ni = (int)nd.size();
         std::vector<int> packed;
@@ -1438,6 +1520,25 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
 }
 
 }  // namespace
+
+// Gives the cached blocks of the current device back to the runtime.
+void ptk_bvh_pool_trim() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> lock(pool::g_mutex);
+        for (size_t i = 0; i < pool::g_free.size();) {
+            if (pool::g_free[i].device != dev) { i++; continue; }
+            drop.push_back(pool::g_free[i].p);
+            if (dev >= 0 && dev < 64) pool::g_held[dev] -= pool::g_free[i].bytes;
+            pool::g_free[i] = pool::g_free.back();
+            pool::g_free.pop_back();
+        }
+    }
+    for (void* p : drop) (void)hipFree(p);
+}
+
 
 // index_tree order + node bytes + object id table (pt_bvh_tree.gd:488-524,780-791,910-959), written to
 // device and/or host memory; with `state`, also everything a later refit needs.
