@@ -277,7 +277,6 @@ void ptk_destroy(ptk_ctx* ctx) {
     }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
-    ptk_bvh_pool_trim();  // what the builder kept of this device's memory for its next build
 }
 
 const char* ptk_last_error(ptk_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }

@@ -57,7 +57,3 @@ std::shared_ptr<PtkBvh> ptk_bvh_build_device(hipStream_t stream, int order, int 
                                              const std::vector<std::shared_ptr<PtkBvh>>& mesh_trees,
                                              const float* mesh_transforms12, const int32_t* mesh_indices,
                                              std::string& err);
-
-// The builder keeps freed device blocks for its next build (per device, up to 1 GiB); this returns those of the
-// current device to the runtime.
-void ptk_bvh_pool_trim();

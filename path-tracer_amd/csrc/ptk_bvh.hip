@@ -26,7 +26,6 @@
 #include <cmath>
 #include <cstring>
 #include <initializer_list>
-#include <mutex>
 
 #include "ptk_bvh.h"
 
@@ -978,77 +977,18 @@ __global__ __launch_bounds__(64) void k_sah_round(const SahSet* sets, int n_sets
 }
 
 // ---- host side -------------------------------------------------------------------------------------------
-// Device allocations of the builder come from a small cache: hipMalloc and hipFree cost 50-200 us each (hipFree
-// waits for the device besides), and a build makes some thirty of them, which was a third of a large build's wall
-// time and most of a small one's.  Freed blocks are kept by size class (powers of two from 4 KiB) and device, up
-// to kPoolBytes per device; ptk_bvh_pool_trim gives them back.
-namespace pool {
-constexpr size_t kPoolBytes = (size_t)1 << 30;
-struct Free { void* p; size_t bytes; int device; unsigned long long stamp; };
-std::mutex g_mutex;
-std::vector<Free> g_free;
-size_t g_held[64] = {0};
-// A block may come back while work that uses it is still queued (an error path, a handle freed right after a call):
-// every return is stamped, and a block is handed out again only after one device-wide wait that is later than its
-// return (one wait covers everything returned before it, so a build costs at most one).
-unsigned long long g_stamp = 0, g_waited_upto = 0;
-size_t size_class(size_t bytes) {
-    size_t c = 4096;
-    while (c < bytes) c <<= 1;
-    return c;
-}
-void* take(size_t bytes, size_t* got) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    const size_t c = size_class(bytes);
-    *got = c;
-    {
-        std::lock_guard<std::mutex> lock(g_mutex);
-        for (size_t i = 0; i < g_free.size(); i++)
-            if (g_free[i].device == dev && g_free[i].bytes == c) {
-                void* p = g_free[i].p;
-                if (g_free[i].stamp > g_waited_upto) {
-                    const unsigned long long now = g_stamp;
-                    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
-                    g_waited_upto = now;
-                }
-                g_free[i] = g_free.back();
-                g_free.pop_back();
-                if (dev >= 0 && dev < 64) g_held[dev] -= c;
-                return p;
-            }
-    }
-    void* p = nullptr;
-    if (hipMalloc(&p, c) != hipSuccess) return nullptr;
-    return p;
-}
-void give(void* p, size_t bytes) {
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-        std::lock_guard<std::mutex> lock(g_mutex);
-        if (g_held[dev] + bytes <= kPoolBytes) {
-            g_free.push_back({p, bytes, dev, ++g_stamp});
-            g_held[dev] += bytes;
-            return;
-        }
-    }
-    (void)hipFree(p);
-}
-}  // namespace pool
-
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
-    size_t cap = 0, bytes = 0;
-    ~DevBuf() { if (p) pool::give(p, bytes); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    size_t cap = 0;
     bool alloc(size_t count) {  // contents are not kept; an allocation that is large enough is reused
         n = count;
         if (p && cap >= std::max<size_t>(count, 1)) return true;
-        if (p) { pool::give(p, bytes); p = nullptr; cap = 0; bytes = 0; }
-        p = (T*)pool::take(std::max<size_t>(count, 1) * sizeof(T), &bytes);
-        if (!p) { cap = 0; bytes = 0; return false; }
-        cap = bytes / sizeof(T);
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        cap = std::max<size_t>(count, 1);
+        if (hipMalloc((void**)&p, cap * sizeof(T)) != hipSuccess) { p = nullptr; cap = 0; return false; }
         return true;
     }
 };
@@ -1520,25 +1460,6 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
 }
 
 }  // namespace
-
-// Gives the cached blocks of the current device back to the runtime.
-void ptk_bvh_pool_trim() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return;
-    std::vector<void*> drop;
-    {
-        std::lock_guard<std::mutex> lock(pool::g_mutex);
-        for (size_t i = 0; i < pool::g_free.size();) {
-            if (pool::g_free[i].device != dev) { i++; continue; }
-            drop.push_back(pool::g_free[i].p);
-            if (dev >= 0 && dev < 64) pool::g_held[dev] -= pool::g_free[i].bytes;
-            pool::g_free[i] = pool::g_free.back();
-            pool::g_free.pop_back();
-        }
-    }
-    for (void* p : drop) (void)hipFree(p);
-}
-
 
 // index_tree order + node bytes + object id table (pt_bvh_tree.gd:488-524,780-791,910-959), written to
 // device and/or host memory; with `state`, also everything a later refit needs.
