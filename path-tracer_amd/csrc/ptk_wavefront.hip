@@ -325,7 +325,9 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
 
 // The bounce-loop body after the closest-hit search (:1583-1621) for every ray of bounce `iter`, and
 // the end of main() (:1683-1704) for the paths that stop here.
-__global__ __launch_bounds__(SHADE_BLOCK) void ptk_wf_shade(const PtkParams P, int iter) {
+// (held to the registers of six waves per SIMD: the kernel waits on dependent gathers -- hit, primitive, material,
+// texture -- so more waves in flight pay; measured 5 / 6 / 7 / 8 waves: 9.03, 8.93, 9.00, 9.15 ms per step)
+__global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void ptk_wf_shade(const PtkParams P, int iter) {
     __shared__ uint32_t s_wave_total[SHADE_BLOCK / 64];
     __shared__ uint32_t s_base;
     const PtkWavefront& W = P.wf;
