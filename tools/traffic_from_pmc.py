@@ -1,5 +1,5 @@
 """profiles/traffic.json from a counter summary of tools/pmc_passes.sh (development aid).
-usage: python tools/traffic_from_pmc.py gpurun_out/pmc_<tag>.json profiles/round2/<tag>_pmc_traverse.json
+usage: python tools/traffic_from_pmc.py gpurun_out/pmc_<tag>.json profiles/<dir>/<tag>_pmc_traverse.json
 Memory-side bytes per launch of the traversal kernel (FETCH_SIZE doubled, the gfx950 correction for 16-byte-per-lane
 loads, plus WRITE_SIZE, both in KiB-like units of 1024 bytes), the L2 hit rate, and how busy the units were that bound
 the kernel: busy cycles summed over the 256 compute units against the launch's cycles (GRBM_GUI_ACTIVE is summed
