@@ -92,7 +92,9 @@ struct ptk_ctx {
     uint32_t n_blocks = 0, n_sockets = 0, n_records = 0;
     bool leaves_hold_triangles = false;  // any triangle in the id table (decides whether long leaves are split, see trav_leaf)
     // host mirrors and maps of the derived structures, for patching them on buffer_update
-    std::vector<float> h_blocks, h_leaf_records;
+    std::vector<float> h_blocks;
+    std::unique_ptr<float[]> h_leaf_records;  // 12 floats per object-id slot; only slots patched since the last validation are set
+    size_t h_leaf_records_slots = 0, d_leaf_records_slots = 0;
     std::vector<int32_t> h_sockets;  // {entry of the mesh's root, transform index} per world-level socket
     uint32_t tree_entry = 0;         // the root node's own entry (root_entry is what follows the chain)
     int n_chain = 0;
@@ -575,7 +577,7 @@ static int flush_updates(ptk_ctx* ctx) {
         idx.clear();
     };
     runs(ctx->dirty_blocks, ctx->block_is_dirty, (uint8_t*)ctx->d_blocks, (const uint8_t*)ctx->h_blocks.data(), 256);
-    runs(ctx->dirty_slots, ctx->slot_is_dirty, (uint8_t*)ctx->d_leaf_records, (const uint8_t*)ctx->h_leaf_records.data(), 48);
+    runs(ctx->dirty_slots, ctx->slot_is_dirty, (uint8_t*)ctx->d_leaf_records, (const uint8_t*)ctx->h_leaf_records.get(), 48);
     if (ctx->live_planes_dirty) {
         if (!ctx->h_live_planes.empty() && ctx->d_live_planes)
             pieces.push_back({(uint8_t*)ctx->d_live_planes, (const uint8_t*)ctx->h_live_planes.data(), ctx->h_live_planes.size() * 4});
@@ -665,10 +667,15 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
             const int32_t slot = slot_of[i];
             if (slot == -1) continue;  // not in any leaf
             if (slot < 0) return 0;    // in several leaves: rebuild
-            float* r = ctx->h_leaf_records.data() + (size_t)slot * 12;
+            if ((size_t)slot >= ctx->h_leaf_records_slots) return 0;
+            float* r = ctx->h_leaf_records.get() + (size_t)slot * 12;
             const uint8_t* p = o->shadow.data() + i * rec;
+            int32_t oid = 0;  // the slot's word of the id table
+            if (Object* idt = bound_buffer(ctx, PTK_SET_BVH, 1)) { if ((size_t)slot * 4 + 4 <= idt->shadow.size()) memcpy(&oid, idt->shadow.data() + (size_t)slot * 4, 4); }
+            memset(r, 0, 48);
             if (tri) { memcpy(r + 0, p + 0, 12); memcpy(r + 4, p + 16, 12); memcpy(r + 8, p + 32, 12); }
             else { memcpy(r + 0, p, 12); memcpy(r + 4, p + 12, 4); }
+            memcpy(r + 3, &oid, 4);
             if (!ctx->slot_is_dirty[slot]) { ctx->slot_is_dirty[slot] = 1; ctx->dirty_slots.push_back((uint32_t)slot); }
         }
         return 1;
@@ -915,32 +922,35 @@ static int validate_scene(ptk_ctx* ctx) {
     if (!sockets.empty()) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sockets, sockets.data(), sockets.size() * 4, hipMemcpyHostToDevice, ctx->stream));
 
     // leaf records: what a leaf tests for object-id slot i, by value, so the traversal kernel reads a
-    // leaf's primitives from consecutive addresses without going through the id table first
-    std::vector<float>& leaf_records = ctx->h_leaf_records;
-    leaf_records.assign((size_t)std::max(n_ids, 1) * 12, 0.0f);
+    // leaf's primitives from consecutive addresses without going through the id table first.  They are made on
+    // the device from the bound buffers (the caller flushed pending edits of those first); the host keeps which
+    // slot a primitive sits in, and a mirror that only ever holds the records patched since (patch_derived).
+    const size_t n_slots = (size_t)std::max(n_ids, 1);
+    if (n_slots > ctx->h_leaf_records_slots) {  // (left unset: a patch writes a slot's whole record before it is read)
+        ctx->h_leaf_records.reset(new float[n_slots * 12]);
+        ctx->h_leaf_records_slots = n_slots;
+    }
     ctx->tri_slot.assign((size_t)n_tri, -1);
     ctx->sph_slot.assign((size_t)n_sph, -1);
     ctx->leaves_hold_triangles = false;
     for (int i = 0; i < n_ids; i++) {
         const int oid = idp[i];
         const int type = sext(oid, 24, 8), oi = sext(oid, 0, 24);
-        float* r = leaf_records.data() + (size_t)i * 12;
         if (type == 3 && oi >= 0 && oi < n_tri) {
-            const uint8_t* t = tri->shadow.data() + (size_t)oi * 80;
-            memcpy(r + 0, t + 0, 12); memcpy(r + 4, t + 16, 12); memcpy(r + 8, t + 32, 12);
-            memcpy(r + 3, &oid, 4);
             ctx->leaves_hold_triangles = true;
             ctx->tri_slot[oi] = ctx->tri_slot[oi] == -1 ? i : -2;  // -2: listed more than once
         } else if (type == 1 && oi >= 0 && oi < n_sph) {
-            const uint8_t* sp = sph->shadow.data() + (size_t)oi * 32;
-            memcpy(r + 0, sp, 12); memcpy(r + 4, sp + 12, 4);
-            memcpy(r + 3, &oid, 4);
             ctx->sph_slot[oi] = ctx->sph_slot[oi] == -1 ? i : -2;
         }
     }
-    if (ctx->d_leaf_records) { (void)hipFree(ctx->d_leaf_records); ctx->d_leaf_records = nullptr; }
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_leaf_records, leaf_records.size() * 4));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_leaf_records, leaf_records.data(), leaf_records.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n_slots > ctx->d_leaf_records_slots) {
+        if (ctx->d_leaf_records) { (void)hipFree(ctx->d_leaf_records); ctx->d_leaf_records = nullptr; }
+        ctx->d_leaf_records_slots = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_leaf_records, n_slots * 48));
+        ctx->d_leaf_records_slots = n_slots;
+    }
+    if (n_ids == 0) HIP_TRY(ctx, hipMemsetAsync(ctx->d_leaf_records, 0, 48, ctx->stream));
+    HIP_TRY(ctx, ptk_launch_leaf_records((const int32_t*)ids->dev, n_ids, tri->dev, n_tri, sph->dev, n_sph, ctx->d_leaf_records, ctx->stream));
 
     // the derived structures were uploaded whole: nothing of them is pending any more
     ctx->dirty_blocks.clear();
@@ -1093,7 +1103,11 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Object* img = find(ctx, ctx->image, Kind::Image);
     if (!img) return fail(ctx, PTK_E_STATE, "no image bound at (0,0)");
-    if (ctx->dirty) { int r = validate_scene(ctx); if (r != PTK_OK) return r; }
+    if (ctx->dirty) {
+        // (validation makes the leaf records on the device, from the bound buffers as the pending edits leave them)
+        { int r = flush_updates(ctx); if (r != PTK_OK) return r; }
+        { int r = validate_scene(ctx); if (r != PTK_OK) return r; }
+    }
     if (ctx->textures_dirty) { int r = refresh_textures(ctx); if (r != PTK_OK) return r; }
     { int r = flush_updates(ctx); if (r != PTK_OK) return r; }
 

@@ -179,3 +179,6 @@ struct PtkScatterEntry {
     uint32_t nbytes;
 };
 extern "C" hipError_t ptk_launch_scatter(const void* d_stage, uint32_t n_entries, hipStream_t stream);
+// Leaf records (48 bytes per object-id slot) from the bound id table, triangle and sphere buffers, all on the device.
+extern "C" hipError_t ptk_launch_leaf_records(const int32_t* ids, int n_ids, const void* triangles80, int n_tri, const void* spheres32, int n_sph,
+                                              void* out48, hipStream_t stream);

@@ -32,3 +32,35 @@ extern "C" hipError_t ptk_launch_scatter(const void* d_stage, uint32_t n_entries
     hipLaunchKernelGGL(ptk_scatter_kernel, dim3(n_entries), dim3(256), 0, stream, (const uint8_t*)d_stage, n_entries);
     return hipGetLastError();
 }
+
+// Leaf records: what a leaf tests for object-id slot i, by value, so that the traversal reads a leaf's primitives
+// from consecutive addresses without going through the id table first.  Triangle: {A.xyz, id} {B.xyz, 0} {C.xyz, 0}
+// from the 80-byte record (pt_triangle.gd:125-150); sphere: {centre.xyz, id} {radius, 0, 0, 0} {0} from the 32-byte
+// record; anything else (and an index outside its buffer, which validation has refused by then) zeros.
+__global__ __launch_bounds__(256) void ptk_leaf_records_kernel(const int32_t* __restrict__ ids, int n_ids, const float4* __restrict__ triangles,
+                                                               int n_tri, const float4* __restrict__ spheres, int n_sph, float4* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ids) return;
+    const int oid = ids[i];
+    const int type = oid >> 24, oi = (int)((uint32_t)oid << 8) >> 8;  // sign-extended fields, as the shader's bitfieldExtract
+    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
+    if (type == 3 && oi >= 0 && oi < n_tri) {
+        const float4 a = triangles[(size_t)oi * 5], b = triangles[(size_t)oi * 5 + 1], c = triangles[(size_t)oi * 5 + 2];
+        r0 = make_float4(a.x, a.y, a.z, __int_as_float(oid));
+        r1 = make_float4(b.x, b.y, b.z, 0.0f);
+        r2 = make_float4(c.x, c.y, c.z, 0.0f);
+    } else if (type == 1 && oi >= 0 && oi < n_sph) {
+        const float4 s = spheres[(size_t)oi * 2];
+        r0 = make_float4(s.x, s.y, s.z, __int_as_float(oid));
+        r1 = make_float4(s.w, 0.0f, 0.0f, 0.0f);
+    }
+    out[(size_t)i * 3] = r0; out[(size_t)i * 3 + 1] = r1; out[(size_t)i * 3 + 2] = r2;
+}
+
+extern "C" hipError_t ptk_launch_leaf_records(const int32_t* ids, int n_ids, const void* triangles80, int n_tri, const void* spheres32, int n_sph,
+                                              void* out48, hipStream_t stream) {
+    if (n_ids <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ptk_leaf_records_kernel, dim3((n_ids + 255) / 256), dim3(256), 0, stream, ids, n_ids, (const float4*)triangles80, n_tri,
+                       (const float4*)spheres32, n_sph, (float4*)out48);
+    return hipGetLastError();
+}
