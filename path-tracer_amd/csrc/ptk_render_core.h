@@ -441,12 +441,12 @@ PTK_DEV Hit check_ray_hit_bvh(const PtkParams& P, Lane& L, Ray& ray, const Stack
 // ---- phase-coherent traversal ------------------------------------------------------------------
 // Same per-lane order of node pops, box tests and object tests as the loop above, but the wave only
 // runs one kind of step at a time: in every round the lanes whose next node is an inner node (or a
-// mesh socket) and the lanes whose next node is a leaf are counted by ballot, and the larger group
-// advances while the other waits.  A lane's own sequence is untouched, so results are identical; the
+// mesh socket) and the lanes whose next node is a leaf are counted by ballot, and one group
+// advances while the other waits (the inner-node lanes unless the leaf lanes outnumber them by half).  A lane's own sequence is untouched, so results are identical; the
 // wave no longer pays the inner-node code and the leaf code in every iteration.  The next node to
 // visit stays in a register (`cur`): the nearest accepted child is not pushed and popped again.
 #ifndef PTK_VOTE_INNER
-#define PTK_VOTE_INNER(ni, nl) ((ni) >= (nl))
+#define PTK_VOTE_INNER(ni, nl) (2 * (ni) >= 3 * (nl))
 #endif
 constexpr uint32_t ENTRY_NONE = 0x7E000000u;  // "inner node with 126 children": never a real entry
 
