@@ -38,6 +38,7 @@ dv, dd = st[200:232], st[232:264]
 rounds = act.sum()
 lanes = (act * np.arange(65)).sum()
 print("inner rounds", rounds, "lane visits", lanes, "mean lanes per round %.1f" % (lanes / rounds))
+print("inner rounds with at most 16 / 24 / 32 / 40 / 48 lanes: " + " / ".join("%.1f %%" % (100.0 * act[:k + 1].sum() / rounds) for k in (16, 24, 32, 40, 48)))
 print("distinct blocks per round: mean %.1f" % ((dist * np.arange(65)).sum() / rounds), " fetches saved by sharing: %.1f %%" % (100 * (1 - (dist * np.arange(65)).sum() / lanes)))
 cum = np.cumsum(grp[::-1])[::-1]
 for g in (2, 4, 8, 16, 32):
