@@ -139,6 +139,7 @@ struct ptk_ctx {
     int lds_window = 32;           // traversal stack entries per lane kept in LDS (PTK_LDS_WINDOW, read once at create)
     bool wf_carry = true;          // the pipeline parks unfinished searches for the next launch (PTK_WF_CARRY=0 turns it off; read once at create)
     int wf_max_lag = 2, wf_park_below = 16;  // (PTK_WF_MAX_LAG, PTK_WF_PARK_BELOW: tuning, read once at create)
+    int leaf_redo_all = 0;         // (PTK_LEAF_REDO_ALL=1: exercises trav_leaf's fallback on every helped leaf; for tests)
     int leaf_split = 4;            // leaves longer than this are shared with a helper lane (PTK_LEAF_SPLIT: tuning, read once at create)
     int wf_wg_claim = 0;           // queue entries per workgroup claim; 0: chosen per scene (PTK_WF_WG_CLAIM, read once at create)
     void* d_wf_carry = nullptr;
@@ -228,6 +229,7 @@ ptk_ctx* ptk_create(int device_ordinal) {
     if (const char* w = getenv("PTK_WF_CARRY")) ctx->wf_carry = atoi(w) != 0;
     if (const char* w = getenv("PTK_WF_MAX_LAG")) ctx->wf_max_lag = std::max(1, std::min(PTK_WF_MAX_LAG, atoi(w)));
     if (const char* w = getenv("PTK_WF_PARK_BELOW")) ctx->wf_park_below = std::max(1, std::min(64, atoi(w)));
+    if (const char* w = getenv("PTK_LEAF_REDO_ALL")) ctx->leaf_redo_all = atoi(w) != 0;
     if (const char* w = getenv("PTK_LEAF_SPLIT")) ctx->leaf_split = std::max(1, std::min(255, atoi(w)));
     if (const char* w = getenv("PTK_WF_WG_CLAIM")) ctx->wf_wg_claim = std::max(1, std::min(64, atoi(w) / 64)) * 64;
     if (const char* c = getenv("PTK_WF_WAVES_PER_CU")) ctx->waves_per_cu_cap = std::max(1, atoi(c));
@@ -1088,6 +1090,7 @@ static void fill_blocks(const ptk_ctx* ctx, PtkParams& P) {
     P.wf.n_blocks = ctx->n_blocks; P.wf.n_sockets = ctx->n_sockets; P.wf.n_records = ctx->n_records;
     // leaves longer than this are shared with a helper lane: worth its set-up for triangle tests, not for sphere tests
     P.wf.leaf_split = ctx->leaves_hold_triangles ? ctx->leaf_split : 255;
+    P.wf.leaf_redo_all = ctx->leaf_redo_all;
     P.wf.leaf_records = ctx->d_leaf_records;
 }
 

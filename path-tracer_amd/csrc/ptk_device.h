@@ -73,6 +73,7 @@ struct PtkWavefront {
     int32_t max_lag;     // launches a path may be behind its bounce number (<= PTK_WF_MAX_LAG)
     int32_t park_below;  // once the queue is dry, a wave parks its searches when at most this many are left (64: at once)
     int32_t leaf_split;  // a leaf of more objects than this is split between its lane and a helper lane (255: never)
+    int32_t leaf_redo_all;  // test switch: every helped leaf is handed back to its owner, as if its helper had met the sphere corner
     uint32_t wg_claim;   // queue entries a traversal workgroup takes from the device-wide counter at a time (a multiple of 64)
     float4* state[2];  // path state travelling with the queue entry, two float4 per entry:
                        // {throughput rgba}, {seed, current_IOR, bits(inside_of_count),

@@ -903,7 +903,7 @@ PTK_DEV void trav_leaf(const PtkParams& P, const Stack& S, Trav& T, bool is_leaf
         h.hit = 1; h.object_id = o_id; h.transform_index = T.cur_xf; h.u = o_u; h.v = o_v;
         r.end = o_end;
     }
-    const bool redo = helped && o_redo;
+    const bool redo = helped && (o_redo || P.wf.leaf_redo_all != 0);
     if (__ballot(redo) != 0ull) {  // (the sphere corner: these owners run their whole leaf alone)
         Ray r2;
         r2.o = T.o; r2.d = T.d; r2.start = T.start; r2.end = T.end;

@@ -177,6 +177,24 @@ def test_spheres_and_triangles_share_leaves(pta, rd, rd_wf, golden_dir):
     _run_case(pta, rd, rd_wf, golden_dir, "spheres+triangles", 320, 184, 6, 4, dispatches=2, scene=scene)
 
 
+def test_helped_leaves_handed_back(pta, golden_dir, monkeypatch):
+    """The fallback of the shared leaves (a helper lane that cannot vouch for its half hands the whole leaf back to
+    its owner) cannot be reached with real spheres; PTK_LEAF_REDO_ALL=1 takes it for every helped leaf.  All three
+    renderers must still give the oracle's image."""
+    monkeypatch.setenv("PTK_LEAF_REDO_ALL", "1")
+    RD = pta.rendering_device
+    scene = pta.scenes.atrium_scene(16384, seed=7)
+    for renderer, pinned in ((RD.PTK_RENDERER_SINGLE_KERNEL, "tile"), (RD.PTK_RENDERER_WAVEFRONT, "wavefront"), (RD.PTK_RENDERER_PERSISTENT, "persistent")):
+        a, b = pta.PtkRenderingDevice(0), pta.PtkRenderingDevice(0)
+        try:
+            b.pinned = pinned
+            b.set_renderer(renderer)
+            _run_case(pta, a, b, golden_dir, "atrium16k, leaves handed back", 320, 184, 6, 4, dispatches=1, scene=scene)
+        finally:
+            a.close()
+            b.close()
+
+
 # ---- size-independent properties at full BASELINE sizes ------------------------------------------
 @pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
 def test_full_size_tiles_equal_whole(pta, rd, rd_wf, golden_dir, w, h):
