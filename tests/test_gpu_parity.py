@@ -195,6 +195,31 @@ def test_helped_leaves_handed_back(pta, golden_dir, monkeypatch):
             b.close()
 
 
+@pytest.mark.parametrize("env", [
+    {"PTK_WF_CARRY": "0"},
+    {"PTK_WF_WG_CLAIM": "64", "PTK_WF_PARK_BELOW": "64"},
+    {"PTK_WF_WG_CLAIM": "1024", "PTK_WF_MAX_LAG": "1", "PTK_WF_PARK_BELOW": "4"},
+    {"PTK_WF_MAX_LAG": "6", "PTK_WF_PARK_BELOW": "40", "PTK_LEAF_SPLIT": "2"},
+    {"PTK_LDS_WINDOW": "12", "PTK_LEAF_SPLIT": "7"},
+], ids=lambda e: ",".join(f"{k[4:].lower()}={v}" for k, v in e.items()))
+def test_pipeline_tuning_variables_do_not_change_the_image(pta, golden_dir, monkeypatch, env):
+    """The pipeline's scheduling knobs (chunk of the queue a workgroup takes, when and how far behind searches are
+    parked, no carry-over at all, a short LDS stack window, where leaves are split) move work around; the image stays
+    the oracle's."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    RD = pta.rendering_device
+    scene = pta.scenes.atrium_scene(16384, seed=7)
+    a, b = pta.PtkRenderingDevice(0), pta.PtkRenderingDevice(0)
+    try:
+        b.pinned = "wavefront"
+        b.set_renderer(RD.PTK_RENDERER_WAVEFRONT)
+        _run_case(pta, a, b, golden_dir, "atrium16k, tuned", 640, 360, 8, 4, dispatches=1, scene=scene)
+    finally:
+        a.close()
+        b.close()
+
+
 # ---- size-independent properties at full BASELINE sizes ------------------------------------------
 @pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
 def test_full_size_tiles_equal_whole(pta, rd, rd_wf, golden_dir, w, h):
