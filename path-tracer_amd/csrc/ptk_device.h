@@ -42,7 +42,7 @@ struct PtkTexDesc {
 #define PTK_WF_MAX_ITER 64
 #define PTK_WF_MAX_LAG 8       // launches a path may fall behind its bounce number by being carried over (see PtkWavefront::carry)
 #define PTK_PP_MAX_WG_WAVES 12  // waves of a path-kernel workgroup (three per SIMD at its register count)
-#define PTK_WF_WG_FLAG_BYTES 16 // LDS words the waves of a traversal workgroup share besides the top blocks: queue dry, waves done
+#define PTK_WF_WG_FLAG_BYTES 16 // LDS words the waves of a workgroup share besides the top blocks: queue dry, waves done, the claim word (wg_claim)
 #define PTK_WF_CARRY_PLANES 25 // words of search state carried besides the stack rows
 // The top of many trees is a chain every ray walks in the same way: a root with one child, a mesh socket, a
 // mesh root with one child (scene root -> PTMesh socket -> mesh tree is the plugin's usual layout).  Those
@@ -132,7 +132,7 @@ extern "C" hipError_t ptk_launch_render(const PtkParams* p, int gx, int gy, int 
                                         size_t lds_bytes, hipStream_t stream);
 // Wavefront renderer: generate, then n_iter x (traverse, shade).  ev[2k], ev[2k+1] (may be null) are
 // recorded around the k-th traversal launch.  n_wgs = persistent traversal workgroups (PTK_WF_WG_WAVES waves each),
-// lds_bytes = their dynamic LDS: n_top * PTK_TOP_BLOCK_STRIDE + PTK_WF_WG_WAVES * (lds_cap + 1) * 256.
+// lds_bytes = their dynamic LDS: n_top * PTK_TOP_BLOCK_STRIDE + PTK_WF_WG_WAVES * (lds_cap + 1) * 256 + PTK_WF_WG_FLAG_BYTES.
 extern "C" hipError_t ptk_launch_wavefront(const PtkParams* p, int gx, int gy, int n_iter, size_t lds_bytes,
                                            int n_wgs, hipEvent_t* ev, hipStream_t stream);
 // Traversal workgroups are PTK_WF_WG_WAVES waves that share one LDS copy of the top blocks; *wgs_per_cu =
