@@ -1828,13 +1828,18 @@ int ptk_image_gather_bands(ptk_ctx* ctx, uint64_t image, const int32_t* first_ro
     const size_t row_floats = (size_t)o->width * 4;
     float* base = (float*)o->dev;
     RCCL_TRY(ctx, r.GroupStart());
+    int rc_in_group = 0;  // (a failed call must not leave the group open)
     if (ctx->comm_rank == root) {
-        for (int k = 0; k < ctx->comm_world; k++)
+        for (int k = 0; k < ctx->comm_world && rc_in_group == 0; k++)
             if (k != root && n_rows[k] > 0)
-                RCCL_TRY(ctx, r.Recv(base + (size_t)first_row[k] * row_floats, (size_t)n_rows[k] * row_floats, kNcclFloat32, k, ctx->comm, ctx->stream));
+                rc_in_group = r.Recv(base + (size_t)first_row[k] * row_floats, (size_t)n_rows[k] * row_floats, kNcclFloat32, k, ctx->comm, ctx->stream);
     } else if (n_rows[ctx->comm_rank] > 0) {
-        RCCL_TRY(ctx, r.Send(base + (size_t)first_row[ctx->comm_rank] * row_floats, (size_t)n_rows[ctx->comm_rank] * row_floats, kNcclFloat32, root,
-                             ctx->comm, ctx->stream));
+        rc_in_group = r.Send(base + (size_t)first_row[ctx->comm_rank] * row_floats, (size_t)n_rows[ctx->comm_rank] * row_floats, kNcclFloat32, root,
+                             ctx->comm, ctx->stream);
+    }
+    if (rc_in_group != 0) {
+        (void)r.GroupEnd();
+        return rccl_fail(ctx, "ncclSend / ncclRecv", rc_in_group);
     }
     RCCL_TRY(ctx, r.GroupEnd());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -851,6 +851,8 @@ PTK_DEV int lane_read_i(int src_lane, int v) { return __builtin_amdgcn_ds_bpermu
 // leaf's start, and its hit replaces the owner's iff its t <= the owner's final ray.end.  A test's t itself
 // depends on ray.end in one corner only -- a sphere whose second root is the smaller one and lies in the range as
 // well (hit_sphere_rec's either_root) -- and a helper that meets it hands the whole leaf back to its owner.
+// (u and v are a triangle hit's; a sphere hit leaves them as they were, and nothing reads them after one -- textured
+// spheres compute their own in determine_rayhit -- so which earlier triangle they stem from is not carried over.)
 // The spare row of the wave's stack window is where owners and helpers find each other.
 PTK_DEV void trav_leaf(const PtkParams& P, const Stack& S, Trav& T, bool is_leaf) {
     int n = 0, base = 0;
