@@ -204,9 +204,10 @@ int ptk_mesh_to_triangles(ptk_ctx* ctx, const ptk_mesh_surface* surface, const f
  * (ptk_mesh_to_triangles' uvs6), and a triangle hit's uv becomes their interpolation
  * (1-u-v)*uv1 + u*uv2 + v*uv3 instead of the barycentric (u,v) themselves: the conversion the shader leaves as
  * a TODO at ray_tracer.comp:1071-1072.  Triangles past the end of the table keep the barycentric uv.
- * PTK_OPT_LAUNCH_TIMING (default 0): with 1, the WAVEFRONT pipeline records a HIP event before and after each
- * of its traversal launches, which ptk_dispatch_traverse_ms reads; each record costs about 3 us of stream time,
- * so it is off unless somebody measures. */
+ * PTK_OPT_LAUNCH_TIMING (default 0): with n > 0, every n-th dispatch of the WAVEFRONT pipeline (the first one
+ * after the call included) records a HIP event before and after each of its traversal launches, which
+ * ptk_dispatch_traverse_ms reads; each record costs about 3 us of stream time, so it is off unless somebody
+ * measures. */
 enum { PTK_OPT_TRIANGLE_UVS = 1, PTK_OPT_LAUNCH_TIMING = 2 };
 int ptk_set_option(ptk_ctx* ctx, int option, int value);
 

@@ -68,7 +68,8 @@ struct ptk_ctx {
     // configuration (ptk_configure)
     int order = 8, refraction_mode = 2, use_emission = 0, early_t_break = 0;
     int opt_triangle_uvs = 0;  // PTK_OPT_TRIANGLE_UVS
-    int opt_launch_timing = 0; // PTK_OPT_LAUNCH_TIMING
+    int opt_launch_timing = 0; // PTK_OPT_LAUNCH_TIMING: 0 off, n > 0: every n-th pipeline dispatch
+    long long wf_dispatches = 0;  // pipeline dispatches since the option was set
     int n_proc = 0;
     int proc_builtin[PTK_MAX_PROC] = {0};
     // derived state, rebuilt when a bound buffer changes
@@ -1337,13 +1338,14 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         P.wf.carry_cap = (uint32_t)cap;
         n_launches = n_iter + ctx->wf_max_lag;  // a parked path runs at most this many launches behind its bounce number
     }
-    if (ctx->opt_launch_timing && !ctx->wf_ev[slot]) {
+    const bool timed = ctx->opt_launch_timing > 0 && (ctx->wf_dispatches++ % ctx->opt_launch_timing) == 0;
+    if (timed && !ctx->wf_ev[slot]) {
         ctx->wf_ev[slot] = new hipEvent_t[2 * PTK_WF_MAX_ITER];
         for (int k = 0; k < 2 * PTK_WF_MAX_ITER; k++) HIP_TRY(ctx, hipEventCreate(&ctx->wf_ev[slot][k]));
     }
     ctx->wf_iters[slot] = n_launches;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
-    ctx->wf_timed[slot] = ctx->opt_launch_timing != 0;
+    ctx->wf_timed[slot] = timed;
     HIP_TRY(ctx, ptk_launch_wavefront(&P, groups_x, groups_y, n_launches, wf_lds, n_wgs, ctx->wf_timed[slot] ? ctx->wf_ev[slot] : nullptr, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
     ctx->dispatch_count++;
@@ -1437,7 +1439,7 @@ int ptk_update_stats(ptk_ctx* ctx, long long* full_validations, long long* patch
 int ptk_set_option(ptk_ctx* ctx, int option, int value) {
     if (!ctx) return PTK_E_INVALID;
     if (option == PTK_OPT_TRIANGLE_UVS) { ctx->opt_triangle_uvs = value ? 1 : 0; return PTK_OK; }
-    if (option == PTK_OPT_LAUNCH_TIMING) { ctx->opt_launch_timing = value ? 1 : 0; return PTK_OK; }
+    if (option == PTK_OPT_LAUNCH_TIMING) { ctx->opt_launch_timing = value > 0 ? value : 0; ctx->wf_dispatches = 0; return PTK_OK; }
     return fail(ctx, PTK_E_INVALID, "unknown option %d", option);
 }
 

@@ -390,8 +390,8 @@ class PtkRenderingDevice:
         self._check(self.lib.ptk_comm_destroy(self.ctx), "ptk_comm_destroy")
 
     def set_option(self, option: int, value: int):
-        """PTK_OPT_* switches (PTK_OPT_TRIANGLE_UVS: interpolate the corner UVs bound at (4,1); PTK_OPT_LAUNCH_TIMING:
-        events around the pipeline's traversal launches, for dispatch_traverse_ms)."""
+        """PTK_OPT_* switches (PTK_OPT_TRIANGLE_UVS: interpolate the corner UVs bound at (4,1); PTK_OPT_LAUNCH_TIMING = n:
+        events around the traversal launches of every n-th pipeline dispatch, for dispatch_traverse_ms)."""
         self._check(self.lib.ptk_set_option(self.ctx, int(option), int(value)), "ptk_set_option")
 
     def set_renderer(self, renderer: int):
