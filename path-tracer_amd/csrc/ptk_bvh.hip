@@ -174,37 +174,59 @@ __global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls,
     A6 acc = a6_zero();
     bool acc_valid = false;  // a6_valid(acc), kept alongside (uniform over the wave)
     int meshes = 0;
-    // The boxes are gathered through perm (two dependent loads); the batch after the current one is already in
-    // flight while the chain below runs, and the indices of the one after that.
-    A6 next_box = a6_zero();
-    int next_kind = 0, next_id = -1;
-    {
-        const int i = call.begin + lane;
-        if (i < call.end) { const int id = perm[i]; next_box = a6_load(in_aabb, id); next_kind = in_kind[id]; }
-        if (i + 64 < call.end) next_id = perm[i + 64];
+    // The boxes are gathered through perm (two dependent loads); the loads of the next LIST_UNROLL batches are in flight
+    // while the current ones are worked on, and the indices of the LIST_UNROLL after them.  (Taking 2 or 4 batches per
+    // turn of the loop measured no faster than 1: a batch that changes nothing costs a handful of comparisons, one that
+    // does, the chain below.)
+#ifndef PTK_LIST_UNROLL
+#define PTK_LIST_UNROLL 1
+#endif
+    constexpr int LIST_UNROLL = PTK_LIST_UNROLL;
+    A6 ahead_box[LIST_UNROLL];
+    int ahead_kind[LIST_UNROLL], ahead_id[LIST_UNROLL];
+#pragma unroll
+    for (int d = 0; d < LIST_UNROLL; d++) {
+        const int i = call.begin + d * 64 + lane;
+        ahead_box[d] = a6_zero();
+        ahead_kind[d] = 0;
+        if (i < call.end) { const int id = perm[i]; ahead_box[d] = a6_load(in_aabb, id); ahead_kind[d] = in_kind[id]; }
+        ahead_id[d] = i + LIST_UNROLL * 64 < call.end ? perm[i + LIST_UNROLL * 64] : -1;
     }
-    for (int base = call.begin; base < call.end; base += 64) {
-        int i = base + lane;
-        bool in = i < call.end;
-        const A6 mine = next_box;
-        const int kind = next_kind;
-        next_box = a6_zero();
-        next_kind = 0;
-        if (next_id >= 0) { next_box = a6_load(in_aabb, next_id); next_kind = in_kind[next_id]; }
-        next_id = i + 128 < call.end ? perm[i + 128] : -1;
+    // The far end of the box as it stands and whether its size has settled (see the skipped batches below); kept
+    // beside acc so that a batch which changes nothing is recognised with a handful of comparisons.
+    float far_x = 0.0f, far_y = 0.0f, far_z = 0.0f;
+    bool settled = false;
+    auto note_box = [&]() {
+        far_x = acc.p[0] + acc.s[0]; far_y = acc.p[1] + acc.s[1]; far_z = acc.p[2] + acc.s[2];
+        settled = acc_valid && __float_as_uint(far_x - acc.p[0]) == __float_as_uint(acc.s[0]) &&
+                  __float_as_uint(far_y - acc.p[1]) == __float_as_uint(acc.s[1]) && __float_as_uint(far_z - acc.p[2]) == __float_as_uint(acc.s[2]);
+    };
+    // one batch of 64 list elements, `mine` this lane's
+    auto batch = [&](const int base, const A6& mine, const int kind) {
+        const int i = base + lane;
+        const bool in = i < call.end;
         meshes += __popcll(__ballot(in && kind == 1));
+        if (settled && base + 64 <= call.end) {
+            // the common case first: a full batch of valid boxes strictly inside the box (valid: finite, no negative
+            // size, not all sizes zero -- a6_valid, given that the comparisons with the box's finite ends hold)
+            const bool quiet = mine.s[0] >= 0.0f && mine.s[1] >= 0.0f && mine.s[2] >= 0.0f &&
+                               !(mine.s[0] == 0.0f && mine.s[1] == 0.0f && mine.s[2] == 0.0f) &&
+                               mine.p[0] > acc.p[0] && mine.p[1] > acc.p[1] && mine.p[2] > acc.p[2] &&
+                               mine.p[0] + mine.s[0] < far_x && mine.p[1] + mine.s[1] < far_y && mine.p[2] + mine.s[2] < far_z;
+            if (__all(quiet)) return;
+        }
         const int cnt = min(64, call.end - base);
         const unsigned long long vmask = __ballot(in && a6_valid(mine));
         int j0 = 0;
         if (!acc_valid) {
             // invalid merged with invalid is the zero box; the first valid element replaces it (pt_utils.gd:34-43)
-            if (vmask == 0ull) { acc = a6_zero(); continue; }
+            if (vmask == 0ull) { acc = a6_zero(); note_box(); return; }
             j0 = __ffsll((long long)vmask) - 1;
             acc = a6_shfl(mine, j0);
             acc_valid = true;
             j0++;
         } else if (vmask == 0ull) {
-            continue;  // a valid box merged with invalid ones stays as it is
+            return;  // a valid box merged with invalid ones stays as it is
         }
         // Fast chain: while the accumulated box stays valid, a step is  e1 = p + s;  p' = min(p, bp);
         // s' = max(e1, bp + bs) - p'  per axis, in list order (the float merge is not associative, so the
@@ -225,9 +247,9 @@ __global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls,
             {
                 const float e1x = px + sx, e1y = py + sy, e1z = pz + sz;
                 const bool inside = mx > px && my > py && mz > pz && e2x < e1x && e2y < e1y && e2z < e1z;
-                const bool settled = __float_as_uint(e1x - px) == __float_as_uint(sx) && __float_as_uint(e1y - py) == __float_as_uint(sy) &&
-                                     __float_as_uint(e1z - pz) == __float_as_uint(sz);
-                if (settled && __all(inside)) continue;
+                const bool settled_now = __float_as_uint(e1x - px) == __float_as_uint(sx) && __float_as_uint(e1y - py) == __float_as_uint(sy) &&
+                                         __float_as_uint(e1z - pz) == __float_as_uint(sz);
+                if (settled_now && __all(inside)) return;
             }
             // A full batch of valid boxes.  The position after element j is the running "p < bp ? p : bp" over the
             // elements up to j, an associative pick (smallest value, the later one among equals) that does not
@@ -289,6 +311,24 @@ __global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls,
             }
             acc_valid = a6_valid(acc);
         }
+        note_box();
+    };
+    for (int base0 = call.begin; base0 < call.end; base0 += 64 * LIST_UNROLL) {
+        A6 cur[LIST_UNROLL];
+        int cur_kind[LIST_UNROLL];
+#pragma unroll
+        for (int d = 0; d < LIST_UNROLL; d++) { cur[d] = ahead_box[d]; cur_kind[d] = ahead_kind[d]; }
+#pragma unroll
+        for (int d = 0; d < LIST_UNROLL; d++) {
+            ahead_box[d] = a6_zero();
+            ahead_kind[d] = 0;
+            if (ahead_id[d] >= 0) { ahead_box[d] = a6_load(in_aabb, ahead_id[d]); ahead_kind[d] = in_kind[ahead_id[d]]; }
+            const int i2 = base0 + (2 * LIST_UNROLL + d) * 64 + lane;
+            ahead_id[d] = i2 < call.end ? perm[i2] : -1;
+        }
+#pragma unroll
+        for (int d = 0; d < LIST_UNROLL; d++)
+            if (base0 + d * 64 < call.end) batch(base0 + d * 64, cur[d], cur_kind[d]);
     }
     if (lane == 0) {
         A6 g = a6_grow(a6_abs(acc), 0.000001f);
