@@ -5,6 +5,8 @@ ids, per-pixel counters and images bit-identical to the CPU oracle, for the one-
 wavefront pipeline."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -72,7 +74,8 @@ def _random_description(seed):
     return dict(bvh_order=8, default_bvh=int(rng.integers(1, 5)), materials=mats, nodes=nodes), rng
 
 
-@pytest.mark.parametrize("seed", range(40))
+# (PTK_FUZZ_SEEDS=n runs more of them: a soak, not part of the regular suite)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PTK_FUZZ_SEEDS", "40"))))
 def test_random_scene(pta, rd, rd_wf, golden_dir, seed):
     desc, rng = _random_description(1000 + seed)
     scene = pta.scenes.scene_from_description(desc)
