@@ -60,27 +60,40 @@ def algorithmic_bytes(cnt, n_planes_padded, pixels):
             + 64 * c["material_fetch"] + pixels * (32 + 128))
 
 
-def measured_traffic(workload):
-    """Memory-side bytes per traversal launch from the committed rocprofv3 PMC passes of this same
-    command (FETCH_SIZE and WRITE_SIZE in separate runs), or None when no pass of this workload is on file."""
+def kernel_source_hash():
+    """Digest of the kernel sources the library is built from (path-tracer_amd/csrc: *.h, *.hip, *.cpp, Makefile):
+    the counter passes on file are stamped with it, so that figures measured on another state of the kernels are
+    not reported as this run's."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "path-tracer_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(base, "*.h")) + glob.glob(os.path.join(base, "*.hip")) +
+                       glob.glob(os.path.join(base, "*.cpp")) + [os.path.join(base, "Makefile")]):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def counter_passes(workload):
+    """The committed rocprofv3 PMC passes of this same command (profiles/traffic.json: FETCH_SIZE, WRITE_SIZE and
+    the SQ / TA / TD groups in separate runs), or (None, why) when they were taken on another workload or another
+    state of the kernel sources."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, "no counter passes on file (profiles/traffic.json)"
     if t.get("workload") != workload:
-        return None
-    return t.get("traverse_bytes_per_launch")
-
-
-def limiter_note():
-    """What the committed PMC passes show to bound the traversal kernel (profiles/traffic.json, key "limiter")."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get("limiter")
-    except (OSError, ValueError):
-        return None
+        return None, "the counter passes on file are of another workload"
+    now = kernel_source_hash()
+    if t.get("source_hash") != now:
+        return None, ("the counter passes on file were taken on another state of path-tracer_amd/csrc (%s, now %s): "
+                      "rerun tools/profile_round.sh" % (t.get("source_hash"), now))
+    return t, None
 
 
 def reference_runtime_note():
@@ -216,6 +229,25 @@ def main():
     kernel_ms = rd.dispatch_history_ms(n_hist)
     traverse_ms = [rd.dispatch_traverse_ms(back) for back in range(n_hist)]  # per dispatch: one duration per launch
 
+    # run-to-run spread: the same K steps twice more, after the region the contract's figures come from
+    rep_s = [elapsed]
+    for _ in range(2):
+        barrier()
+        t_rep = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        rep_s.append(time.perf_counter() - t_rep)
+
+    # who ran where: one entry per rank (the launcher's numbering, the GPU it rendered on)
+    props = torch.cuda.get_device_properties(device_index)
+    me = {"rank": rank, "local_rank": local_rank, "device": device_index, "name": props.name,
+          "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))}
+    ranks = [me]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, me)
+        ranks = gathered
+
     # The other partitioning (N > 1 only, reported beside the contract's figures): every rank renders its band
     # of tile rows of the SAME samples and rank 0 gathers the bands -- strong scaling of one frame, bit-identical
     # to a one-GPU render.
@@ -270,6 +302,37 @@ def main():
             dist.all_reduce(tc, op=dist.ReduceOp.MAX)
             c_abi_comm = {"ms_per_step": float(tc[0].item()) / args.steps * 1e3, "steps": args.steps,
                           "note": "sample batches with ptk_image_reduce_mean (RCCL called by libptk) instead of torch.distributed"}
+            # tile rows through the C ABI as well: every rank renders its band, ptk_image_gather_bands assembles them on rank 0
+            bands = mg.row_bands(HEIGHT // 8, world)
+            first_row = [b[0] * 8 for b in bands]
+            n_rows = [b[1] * 8 for b in bands]
+            band_c = mg.band_window(win, rank, world)
+
+            def run_c_bands(n):
+                for k in range(n):
+                    band_c.frame = k
+                    disp.create_compute_list(band_c, scene.camera, wd.sample_time(k))
+                rd.image_gather_bands(disp.image_buffer, first_row, n_rows, 0)
+
+            run_c_bands(1)
+            barrier()
+            t_c = time.perf_counter()
+            run_c_bands(args.steps)
+            barrier()
+            tc = torch.tensor([time.perf_counter() - t_c], dtype=torch.float64, device=f"cuda:{device_index}")
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            c_abi_comm["tile_rows_ms_per_frame"] = float(tc[0].item()) / args.steps * 1e3
+            if rank == 0:
+                # the gathered frame equals the last sample rendered whole on this GPU (bit for bit)
+                gathered_img = rd.texture_get_data(disp.image_buffer)
+                whole = wd.PTRenderWindow(render_width=WIDTH, render_height=HEIGHT, max_ray_depth=DEPTH,
+                                          max_refraction_bounces=REFRACTION_BOUNCES, max_samples=args.steps)
+                for k in range(args.steps):
+                    whole.frame = k
+                    disp.create_compute_list(whole, scene.camera, wd.sample_time(k))
+                rd.sync()
+                c_abi_comm["tile_rows_bit_identical_to_one_gpu"] = bool(np.array_equal(gathered_img.view(np.uint32),
+                                                                                      rd.texture_get_data(disp.image_buffer).view(np.uint32)))
             rd.comm_destroy()
         except Exception as exc:  # noqa: BLE001
             c_abi_comm = {"error": repr(exc)}
@@ -301,7 +364,18 @@ def main():
     achieved_gbs = trav_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     step_bytes = algorithmic_bytes(cnt, n_planes_padded, pixels * args.steps) / args.steps
     step_gbs = step_bytes / (avg_step_ms * 1e-3) / 1e9
-    traffic = measured_traffic(workload)
+    passes, passes_note = counter_passes(workload)
+    traffic = passes.get("traverse_bytes_per_launch") if passes else None
+    binding = None
+    if passes and passes.get("limiter"):
+        lim = passes["limiter"]
+        if lim.get("valu_busy") is not None and lim.get("lane_fraction") is not None:
+            binding = {"bound": "valu_issue", "achieved": lim["valu_busy"], "peak": 1.0, "unit": "fraction of VALU issue cycles",
+                       "lane_fraction": lim["lane_fraction"], "effective": lim["valu_busy"] * lim["lane_fraction"],
+                       "note": "achieved = SQ_ACTIVE_INST_VALU * 4 / (SIMDs * cycles) of the traversal launches; lane_fraction = "
+                               "SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64), the share of the 64 lanes that an issued VALU instruction "
+                               "works for; effective = their product, the share of the chip's lane-cycles doing arithmetic",
+                       "source": lim.get("source")}
     out = {
         "metric": "Mrays/s (path segments/s) at 1920x1080 Sponza (synthetic 262144-triangle stand-in: the reference's .blend is not in its checkout)",
         "value": rays_total / elapsed / 1e6,
@@ -310,6 +384,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step_min": min(rep_s) / args.steps * 1e3,
+        "ms_per_step_max": max(rep_s) / args.steps * 1e3,
+        "repetitions": len(rep_s),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -322,6 +399,8 @@ def main():
             "bvh_nodes": len(disp.packed.bvh) // 32, "bvh_build_s": build_s,
             "parallelism": "sample batches per GPU, scene replicated, RCCL reduce of accumulators" if world > 1 else "single GPU",
         },
+        "ranks": ranks,
+        "collective_backend": None if world == 1 else ("gloo" if rehearsal else "nccl (RCCL), world size %d" % world),
         **({"rehearsal": True, "rehearsal_note": "ranks share GPU 0 and reduce over gloo: control flow only, not a scaling figure"} if rehearsal and world > 1 else {}),
         "roofline": {
             "bound": "hbm",
@@ -331,11 +410,14 @@ def main():
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
+            **({"traffic_note": passes_note} if passes_note else {}),
+            # what the counter passes show to bind the kernel: VALU issue, at the measured share of working lanes
+            "binding": binding,
             # `achieved` prices the reference layout's bytes with no cache credit, as the metric is defined; what
             # the memory side really moved per launch, and the units that limit the kernel, are stated beside it
             "hbm_measured": None if traffic is None else {"bytes_per_launch": traffic, "gbs": traffic / (avg_launch_ms * 1e-3) / 1e9,
                                                           "frac_of_peak": traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "limiter": limiter_note(),
+            "limiter": passes.get("limiter") if passes else None,
             "note": "achieved prices every box and primitive test at the reference layout's bytes with no cache credit, as the metric is defined; "
                     "the scene's tree stays in LDS / L2, so the figure can pass the HBM peak (frac > 1): hbm_measured is what the memory side moved",
             "bytes_per_launch": trav_bytes_per_launch,

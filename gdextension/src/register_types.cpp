@@ -1,10 +1,12 @@
-// register_types.cpp -- GDExtension entry point: registers PtkRenderingDevice at the scene level.
+// register_types.cpp -- GDExtension entry point: registers PtkRenderingDevice (the C ABI, method for method) and
+// PtkGodotRenderingDevice (RenderingDevice's own signatures) at the scene level.
 #include <gdextension_interface.h>
 
 #include <godot_cpp/core/class_db.hpp>
 #include <godot_cpp/core/defs.hpp>
 #include <godot_cpp/godot.hpp>
 
+#include "ptk_godot_rd.h"
 #include "ptk_rendering_device.h"
 
 using namespace godot;
@@ -12,6 +14,7 @@ using namespace godot;
 static void initialize_ptk_module(ModuleInitializationLevel p_level) {
     if (p_level != MODULE_INITIALIZATION_LEVEL_SCENE) return;
     ClassDB::register_class<PtkRenderingDevice>();
+    ClassDB::register_class<PtkGodotRenderingDevice>();
 }
 
 static void uninitialize_ptk_module(ModuleInitializationLevel p_level) { (void)p_level; }

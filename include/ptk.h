@@ -35,6 +35,7 @@ enum {
 /* (set, binding) contract of shaders/ray_tracer.comp:364-414 and
  * proprietary_dataclasses/pt_work_dispatcher.gd:76-109. */
 enum {
+    PTK_SET_NONE = -1,    /* ptk_buffer_create: not bound yet (ptk_buffer_bind places it) */
     PTK_SET_IMAGE = 0,
     PTK_SET_OBJECT = 2,   /* bindings: 0 materials, 1 spheres, 2 planes, 3 triangles */
     PTK_SET_BVH = 3,      /* bindings: 0 nodes, 1 object ids */
@@ -68,6 +69,28 @@ const char* ptk_last_error(ptk_ctx* ctx);
  * files (checker_board.comp, checker_board_spatial.comp) are accepted. */
 int ptk_configure(ptk_ctx* ctx, int bvh_order, int refraction_mode, int use_emission, int early_t_break,
                   const char* const* proc_tex_paths, int n_paths);
+/* The same selection for a host that keeps PTWorkDispatcher.load_shader as it is (pt_work_dispatcher.gd:436-445):
+ * replaces rd.shader_compile_spirv_from_source + shader_create_from_spirv + compute_pipeline_create, taking the
+ * GLSL text of RDShaderSource.source_compute as PTUtils.load_shader edited it (pt_utils.gd:140-195).  Nothing is
+ * compiled: the `order` constant, the #define switches use_refraction_tracking / USE_EMISSION / use_early_t_break
+ * and the spliced _procedural_texture_function<i> definitions are read from the text, and each spliced function
+ * is matched, by a digest of its source without comments and white space, to one of the built-in functions (the
+ * two files the plugin ships, plus whatever ptk_register_procedural_texture added).  A function that matches
+ * none is PTK_E_UNSUPPORTED; a text without the `order` line is PTK_E_INVALID. */
+int ptk_configure_from_source(ptk_ctx* ctx, const char* source, size_t nbytes);
+/* What ptk_configure_from_source reads from a source text, without applying it (ctx may be NULL: then only the
+ * shipped files are recognised): info21 = {order, refraction_mode, use_emission, early_t_break, n_procedural,
+ * built-in function of procedural texture 1..16 (1 checker_board, 2 checker_board_spatial, 0 unknown)}.
+ * No counterpart in the reference. */
+int ptk_shader_source_info(ptk_ctx* ctx, const char* source, size_t nbytes, int32_t* info21);
+/* Lets ptk_configure_from_source recognise another procedural-texture file as one of the built-in functions:
+ * text = the file as written (a GLSL function `vec4 procedural_texture(vec3 pos)` with whatever it declares in
+ * front), builtin_path = the shipped file whose function it computes ("checker_board.comp" or
+ * "checker_board_spatial.comp").  For scenes whose texture files are copies or re-formattings of the shipped
+ * ones; the library does not check that the two functions agree.  No counterpart in the reference, where the
+ * driver compiles whatever the file holds.  ptk_procedural_texture_digest returns the digest used for the match. */
+int ptk_register_procedural_texture(ptk_ctx* ctx, const char* text, size_t nbytes, const char* builtin_path);
+int ptk_procedural_texture_digest(const char* text, size_t nbytes, uint64_t* digest);
 
 /* Replaces rd.storage_buffer_create + RDUniform binding + uniform_set_create,
  * pt_work_dispatcher.gd:642-653 and :408-433.  Creating a buffer for a
@@ -75,6 +98,12 @@ int ptk_configure(ptk_ctx* ctx, int bvh_order, int refraction_mode, int use_emis
  * valid until freed), as PTWorkDispatcher does when it grows a buffer
  * (:511-637). */
 uint64_t ptk_buffer_create(ptk_ctx* ctx, int set, int binding, const void* bytes, size_t nbytes);
+/* Replaces rd.uniform_set_create + compute_list_bind_uniform_set for one uniform (pt_work_dispatcher.gd:408-433,
+ * 482-487) when the buffer was created without a place (set = PTK_SET_NONE, as rd.storage_buffer_create(size, bytes)
+ * creates it, :643): from now on the kernels read `handle` at (set, binding).  Also takes an image handle for
+ * (0,0).  Binding what is bound there already changes nothing (the plugin binds every set before every
+ * dispatch); a buffer sits at one place at a time. */
+int ptk_buffer_bind(ptk_ctx* ctx, uint64_t handle, int set, int binding);
 /* Replaces rd.buffer_update, proprietary_dataclasses/pt_renderer.gd:664-697,771-788. */
 int ptk_buffer_update(ptk_ctx* ctx, uint64_t buffer, size_t offset, const void* bytes, size_t nbytes);
 /* Replaces rd.buffer_get_data (used by the reference only while debugging); reads a buffer back. */
@@ -102,6 +131,10 @@ int ptk_image_update(ptk_ctx* ctx, uint64_t image, const void* src, size_t nbyte
  * RGBA32F level-0 data for slot `slot` of the 512-entry sampler array; rgba
  * NULL selects the 8x8 filler grid (:350-370). */
 uint64_t ptk_texture_create(ptk_ctx* ctx, int slot, int width, int height, const float* rgba);
+/* Places a texture created with slot = -1 into slot `slot` of the sampler array: the uniform.add_id(sampler),
+ * uniform.add_id(texture) pairs of create_texture_buffers (pt_work_dispatcher.gd:314-345) once their uniform set
+ * is bound.  One texture may fill many slots (the plugin's filler fills every unused one). */
+int ptk_texture_bind(ptk_ctx* ctx, uint64_t texture, int slot);
 
 /* Replaces compute_list_begin .. compute_list_dispatch .. compute_list_end,
  * pt_work_dispatcher.gd:470-497.  push128 is the 128-byte push constant block

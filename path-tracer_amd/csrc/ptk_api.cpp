@@ -20,6 +20,7 @@
 
 #include "ptk_bvh.h"
 #include "ptk_device.h"
+#include "ptk_source.h"
 
 namespace {
 
@@ -72,6 +73,7 @@ struct ptk_ctx {
     long long wf_dispatches = 0;  // pipeline dispatches since the option was set
     int n_proc = 0;
     int proc_builtin[PTK_MAX_PROC] = {0};
+    std::vector<std::pair<uint64_t, int>> proc_registered;  // ptk_register_procedural_texture: digest -> PTK_PROC_*
     // derived state, rebuilt when a bound buffer changes
     bool dirty = true;
     int stack_need = 1;
@@ -293,29 +295,92 @@ static bool ends_with(const std::string& s, const char* suffix) {
     return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
 }
 
-int ptk_configure(ptk_ctx* ctx, int bvh_order, int refraction_mode, int use_emission, int early_t_break,
-                  const char* const* proc_tex_paths, int n_paths) {
-    if (!ctx) return PTK_E_INVALID;
+// PTK_PROC_* of a texture_path as ptk_configure takes it, 0 if it names neither shipped file.
+static int builtin_of_path(const char* path) {
+    const std::string p = path ? path : "";
+    if (ends_with(p, "checker_board_spatial.comp")) return PTK_PROC_CHECKER_BOARD_SPATIAL;
+    if (ends_with(p, "checker_board.comp")) return PTK_PROC_CHECKER_BOARD;
+    return 0;
+}
+
+static int apply_configuration(ptk_ctx* ctx, int bvh_order, int refraction_mode, int use_emission, int early_t_break,
+                               const int* builtin, int n_proc) {
     if (bvh_order < 2) return fail(ctx, PTK_E_INVALID, "bvh_order must be >= 2 (got %d)", bvh_order);
     if (bvh_order > PTK_MAX_WIDTH)
         return fail(ctx, PTK_E_UNSUPPORTED, "bvh_order %d is wider than the %d the kernels are built for", bvh_order, PTK_MAX_WIDTH);
     if (refraction_mode < 0 || refraction_mode > 2) return fail(ctx, PTK_E_INVALID, "refraction_mode must be 0, 1 or 2");
-    if (n_paths < 0 || n_paths > PTK_MAX_PROC) return fail(ctx, PTK_E_UNSUPPORTED, "at most %d procedural textures", PTK_MAX_PROC);
-    int builtin[PTK_MAX_PROC] = {0};
-    for (int i = 0; i < n_paths; i++) {
-        std::string p = proc_tex_paths && proc_tex_paths[i] ? proc_tex_paths[i] : "";
-        if (ends_with(p, "checker_board_spatial.comp")) builtin[i] = PTK_PROC_CHECKER_BOARD_SPATIAL;
-        else if (ends_with(p, "checker_board.comp")) builtin[i] = PTK_PROC_CHECKER_BOARD;
-        else return fail(ctx, PTK_E_UNSUPPORTED, "procedural texture '%s' is not one of the built-in functions", p.c_str());
-    }
     ctx->order = bvh_order;
     ctx->refraction_mode = refraction_mode;
     ctx->use_emission = use_emission ? 1 : 0;
     ctx->early_t_break = early_t_break ? 1 : 0;
-    ctx->n_proc = n_paths;
-    memcpy(ctx->proc_builtin, builtin, sizeof builtin);
+    ctx->n_proc = n_proc;
+    memset(ctx->proc_builtin, 0, sizeof ctx->proc_builtin);
+    for (int i = 0; i < n_proc; i++) ctx->proc_builtin[i] = builtin[i];
     ctx->dirty = true;
     return PTK_OK;
+}
+
+int ptk_configure(ptk_ctx* ctx, int bvh_order, int refraction_mode, int use_emission, int early_t_break,
+                  const char* const* proc_tex_paths, int n_paths) {
+    if (!ctx) return PTK_E_INVALID;
+    if (n_paths < 0 || n_paths > PTK_MAX_PROC) return fail(ctx, PTK_E_UNSUPPORTED, "at most %d procedural textures", PTK_MAX_PROC);
+    int builtin[PTK_MAX_PROC] = {0};
+    for (int i = 0; i < n_paths; i++) {
+        const char* p = proc_tex_paths && proc_tex_paths[i] ? proc_tex_paths[i] : "";
+        builtin[i] = builtin_of_path(p);
+        if (!builtin[i]) return fail(ctx, PTK_E_UNSUPPORTED, "procedural texture '%s' is not one of the built-in functions", p);
+    }
+    return apply_configuration(ctx, bvh_order, refraction_mode, use_emission, early_t_break, builtin, n_paths);
+}
+
+int ptk_procedural_texture_digest(const char* text, size_t nbytes, uint64_t* digest) {
+    if (!digest) return PTK_E_INVALID;
+    std::string err;
+    if (!ptk_source::file_digest(text, nbytes, *digest, err)) return fail(nullptr, PTK_E_INVALID, "%s", err.c_str());
+    return PTK_OK;
+}
+
+int ptk_register_procedural_texture(ptk_ctx* ctx, const char* text, size_t nbytes, const char* builtin_path) {
+    if (!ctx) return PTK_E_INVALID;
+    const int b = builtin_of_path(builtin_path);
+    if (!b) return fail(ctx, PTK_E_UNSUPPORTED, "'%s' is not one of the built-in functions", builtin_path ? builtin_path : "");
+    uint64_t d = 0;
+    std::string err;
+    if (!ptk_source::file_digest(text, nbytes, d, err)) return fail(ctx, PTK_E_INVALID, "%s", err.c_str());
+    for (auto& kv : ctx->proc_registered) if (kv.first == d) { kv.second = b; return PTK_OK; }
+    ctx->proc_registered.push_back({d, b});
+    return PTK_OK;
+}
+
+// info = {order, refraction_mode, use_emission, early_t_break, n_proc, builtin[PTK_MAX_PROC]} (builtin 0: not recognised)
+static int read_shader_source(ptk_ctx* ctx, const char* source, size_t nbytes, int32_t* info) {
+    ptk_source::Info si;
+    std::string err;
+    if (!ptk_source::parse_shader(source, nbytes, si, err)) return fail(ctx, PTK_E_INVALID, "%s", err.c_str());
+    info[0] = si.order; info[1] = si.refraction_mode; info[2] = si.use_emission; info[3] = si.early_t_break; info[4] = si.n_proc;
+    for (int i = 0; i < PTK_MAX_PROC; i++) {
+        int b = i < si.n_proc ? ptk_source::builtin_of_digest(si.digest[i]) : 0;
+        if (i < si.n_proc && !b && ctx)
+            for (auto& kv : ctx->proc_registered) if (kv.first == si.digest[i]) b = kv.second;
+        info[5 + i] = b;
+    }
+    return PTK_OK;
+}
+
+int ptk_shader_source_info(ptk_ctx* ctx, const char* source, size_t nbytes, int32_t* info21) {
+    if (!info21) return PTK_E_INVALID;
+    return read_shader_source(ctx, source, nbytes, info21);
+}
+
+int ptk_configure_from_source(ptk_ctx* ctx, const char* source, size_t nbytes) {
+    if (!ctx) return PTK_E_INVALID;
+    int32_t info[5 + PTK_MAX_PROC];
+    { int r = read_shader_source(ctx, source, nbytes, info); if (r != PTK_OK) return r; }
+    for (int i = 0; i < info[4]; i++)
+        if (!info[5 + i])
+            return fail(ctx, PTK_E_UNSUPPORTED, "procedural texture function %d of the shader source is not one of the built-in functions "
+                                                "(and was not registered with ptk_register_procedural_texture)", i + 1);
+    return apply_configuration(ctx, info[0], info[1], info[2], info[3], info + 5, info[4]);
 }
 
 uint64_t ptk_buffer_create(ptk_ctx* ctx, int set, int binding, const void* bytes, size_t nbytes) {
@@ -340,10 +405,41 @@ uint64_t ptk_buffer_create(ptk_ctx* ctx, int set, int binding, const void* bytes
     }
     uint64_t h = ctx->next_handle++;
     ctx->objects[h] = std::move(o);
+    if (set == PTK_SET_NONE) return h;  // bound later (ptk_buffer_bind): nothing the kernels read has changed
     ctx->bound[{set, binding}] = h;
     if (set == PTK_SET_BVH) ctx->bound_tree.reset();  // another tree is bound now
     ctx->dirty = true;
     return h;
+}
+
+int ptk_buffer_bind(ptk_ctx* ctx, uint64_t handle, int set, int binding) {
+    if (!ctx) return PTK_E_INVALID;
+    auto it = ctx->objects.find(handle);
+    if (it == ctx->objects.end()) return fail(ctx, PTK_E_INVALID, "unknown handle %llu", (unsigned long long)handle);
+    Object* o = it->second.get();
+    if (o->kind == Kind::Image) {
+        if (set != PTK_SET_IMAGE || binding != 0) return fail(ctx, PTK_E_INVALID, "an image binds at (0,0) only (got (%d,%d))", set, binding);
+        ctx->image = handle;
+        return PTK_OK;
+    }
+    if (o->kind != Kind::Buffer) return fail(ctx, PTK_E_INVALID, "handle %llu is neither a storage buffer nor an image", (unsigned long long)handle);
+    const bool known = (set == PTK_SET_OBJECT && binding >= 0 && binding <= 3) || (set == PTK_SET_BVH && binding >= 0 && binding <= 1) ||
+                       (set == PTK_SET_TRIANGLE && binding >= 0 && binding <= 2) || (set == PTK_SET_TRANSFORM && binding == 0);
+    if (!known) return fail(ctx, PTK_E_INVALID, "the shader has no storage buffer at (%d,%d)", set, binding);
+    auto cur = ctx->bound.find({set, binding});
+    if (cur != ctx->bound.end() && cur->second == handle) return PTK_OK;  // as it was: derived data stays valid
+    // a buffer sits at one (set, binding) at a time: binding it elsewhere takes it out of its old place
+    for (auto b = ctx->bound.begin(); b != ctx->bound.end();) {
+        if (b->second == handle) b = ctx->bound.erase(b);
+        else ++b;
+    }
+    ctx->bound[{set, binding}] = handle;
+    o->set = set;
+    o->binding = binding;
+    if (set == PTK_SET_BVH && ctx->bound_tree && handle != ctx->bound_tree->nodes_handle && handle != ctx->bound_tree->ids_handle)
+        ctx->bound_tree.reset();  // another tree is bound now
+    ctx->dirty = true;
+    return PTK_OK;
 }
 
 int ptk_buffer_update(ptk_ctx* ctx, uint64_t buffer, size_t offset, const void* bytes, size_t nbytes) {
@@ -447,7 +543,7 @@ int ptk_image_update(ptk_ctx* ctx, uint64_t image, const void* src, size_t nbyte
 
 uint64_t ptk_texture_create(ptk_ctx* ctx, int slot, int width, int height, const float* rgba) {
     if (!ctx) return 0;
-    if (slot < 0 || slot >= 512) { fail(ctx, PTK_E_INVALID, "texture slot %d out of range (0..511)", slot); return 0; }
+    if (slot < -1 || slot >= 512) { fail(ctx, PTK_E_INVALID, "texture slot %d out of range (0..511, or -1 for none)", slot); return 0; }
     if (rgba && (width <= 0 || height <= 0)) { fail(ctx, PTK_E_INVALID, "bad texture size"); return 0; }
     if (hipSetDevice(ctx->device) != hipSuccess) { fail(ctx, PTK_E_HIP, "hipSetDevice failed"); return 0; }
     auto o = std::make_unique<Object>();
@@ -467,9 +563,23 @@ uint64_t ptk_texture_create(ptk_ctx* ctx, int slot, int width, int height, const
     }
     uint64_t h = ctx->next_handle++;
     ctx->objects[h] = std::move(o);
+    if (slot < 0) return h;  // placed later (ptk_texture_bind)
     ctx->texture_slots[slot] = h;
     ctx->textures_dirty = true;
     return h;
+}
+
+int ptk_texture_bind(ptk_ctx* ctx, uint64_t texture, int slot) {
+    if (!ctx) return PTK_E_INVALID;
+    if (slot < 0 || slot >= 512) return fail(ctx, PTK_E_INVALID, "texture slot %d out of range (0..511)", slot);
+    Object* o = find(ctx, texture, Kind::Texture);
+    if (!o) return fail(ctx, PTK_E_INVALID, "unknown texture handle %llu", (unsigned long long)texture);
+    auto cur = ctx->texture_slots.find(slot);
+    if (cur != ctx->texture_slots.end() && cur->second == texture) return PTK_OK;
+    ctx->texture_slots[slot] = texture;  // (one texture may fill many slots, as the plugin's filler does)
+    o->slot = slot;
+    ctx->textures_dirty = true;
+    return PTK_OK;
 }
 
 int ptk_free(ptk_ctx* ctx, uint64_t handle) {

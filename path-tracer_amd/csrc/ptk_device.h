@@ -15,6 +15,10 @@
 #define PTK_PROC_CHECKER_BOARD 1
 #define PTK_PROC_CHECKER_BOARD_SPATIAL 2
 #define PTK_MAX_PROC 16
+// Digests (ptk_procedural_texture_digest) of those two files as the plugin ships them; tools/proc_texture_digests.py
+// prints them from a checkout of the plugin.
+#define PTK_DIGEST_CHECKER_BOARD 0x796fdc7af7a91a27ull
+#define PTK_DIGEST_CHECKER_BOARD_SPATIAL 0x317ca6e7441a9819ull
 
 // Push constant block, ray_tracer.comp:416-434 (128 bytes).
 struct PtkPush {

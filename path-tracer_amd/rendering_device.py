@@ -33,11 +33,14 @@ EXPORTS = [
     "ptk_set_renderer", "ptk_dispatch_traverse_ms", "ptk_update_stats", "ptk_dispatch_noalloc",
     "ptk_image_read_display", "ptk_mesh_to_triangles", "ptk_set_option",
     "ptk_bvh_bind", "ptk_bvh_refit",
+    "ptk_buffer_bind", "ptk_texture_bind", "ptk_configure_from_source", "ptk_shader_source_info",
+    "ptk_register_procedural_texture", "ptk_procedural_texture_digest",
 ]
 
 PTK_RENDERER_AUTO, PTK_RENDERER_SINGLE_KERNEL, PTK_RENDERER_WAVEFRONT, PTK_RENDERER_PERSISTENT = 0, 1, 2, 3
 
 PTK_REFIT_MESH = 4
+PTK_SET_NONE = -1
 PTK_OPT_TRIANGLE_UVS, PTK_OPT_LAUNCH_TIMING = 1, 2
 
 
@@ -81,6 +84,18 @@ def load_library() -> C.CDLL:
     lib.ptk_configure.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_int]
     lib.ptk_buffer_create.restype = u64
     lib.ptk_buffer_create.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
+    lib.ptk_buffer_bind.restype = C.c_int
+    lib.ptk_buffer_bind.argtypes = [vp, u64, C.c_int, C.c_int]
+    lib.ptk_texture_bind.restype = C.c_int
+    lib.ptk_texture_bind.argtypes = [vp, u64, C.c_int]
+    lib.ptk_configure_from_source.restype = C.c_int
+    lib.ptk_configure_from_source.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.ptk_shader_source_info.restype = C.c_int
+    lib.ptk_shader_source_info.argtypes = [vp, C.c_char_p, C.c_size_t, i32p]
+    lib.ptk_register_procedural_texture.restype = C.c_int
+    lib.ptk_register_procedural_texture.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p]
+    lib.ptk_procedural_texture_digest.restype = C.c_int
+    lib.ptk_procedural_texture_digest.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)]
     lib.ptk_buffer_update.restype = C.c_int
     lib.ptk_buffer_update.argtypes = [vp, u64, C.c_size_t, vp, C.c_size_t]
     lib.ptk_buffer_read.restype = C.c_int
@@ -189,6 +204,22 @@ class PtkRenderingDevice:
         self._check(self.lib.ptk_configure(self.ctx, bvh_order, refraction_mode, int(use_emission), int(early_t_break),
                                            arr, len(proc_tex_paths)), "ptk_configure")
 
+    def configure_from_source(self, source: str):
+        """The same selection from the GLSL text PTUtils.load_shader produces (ptk_configure_from_source)."""
+        b = source.encode() if isinstance(source, str) else bytes(source)
+        self._check(self.lib.ptk_configure_from_source(self.ctx, b, len(b)), "ptk_configure_from_source")
+
+    def shader_source_info(self, source: str) -> dict:
+        b = source.encode() if isinstance(source, str) else bytes(source)
+        info = (C.c_int32 * 21)()
+        self._check(self.lib.ptk_shader_source_info(self.ctx, b, len(b), info), "ptk_shader_source_info")
+        return {"order": info[0], "refraction_mode": info[1], "use_emission": info[2], "early_t_break": info[3],
+                "builtins": [info[5 + i] for i in range(info[4])]}
+
+    def register_procedural_texture(self, text: str, builtin_path: str):
+        b = text.encode() if isinstance(text, str) else bytes(text)
+        self._check(self.lib.ptk_register_procedural_texture(self.ctx, b, len(b), builtin_path.encode()), "ptk_register_procedural_texture")
+
     # -- buffers -----------------------------------------------------------
     def storage_buffer_create(self, set_index: int, binding: int, data) -> int:
         b = _as_bytes(data)
@@ -196,6 +227,13 @@ class PtkRenderingDevice:
         if not h:
             raise PtkError("ptk_buffer_create failed: " + self._err())
         return h
+
+    def buffer_bind(self, handle: int, set_index: int, binding: int):
+        """Places a buffer created with set_index PTK_SET_NONE (or an image, at (0,0))."""
+        self._check(self.lib.ptk_buffer_bind(self.ctx, handle, set_index, binding), "ptk_buffer_bind")
+
+    def texture_bind(self, texture: int, slot: int):
+        self._check(self.lib.ptk_texture_bind(self.ctx, texture, slot), "ptk_texture_bind")
 
     def buffer_update(self, buffer: int, offset: int, size_bytes: int, data):
         b = _as_bytes(data)

@@ -19,6 +19,32 @@ HARNESS = os.path.join(HERE, "c_abi", "c_abi_harness")
 FIXTURE = os.path.join(HERE, "golden", "c_harness_sphere_scene1.bin")
 
 
+def test_rd_core_harness_matches_oracle(pta, tmp_path):
+    """The Godot-free core of the GDExtension class (gdextension/src/ptk_rd_core.h) driven like a RenderingDevice from
+    C++: shader from source text, unplaced resources, uniform sets with the 512 filler pairs, a compute list
+    dispatched twice.  Its image equals the oracle's."""
+    from godot_style_dispatcher import SHADER_TEMPLATE, load_shader_source
+    harness = os.path.join(HERE, "c_abi", "rd_core_harness")
+    assert os.path.exists(harness), "tests/c_abi/rd_core_harness is built by __graft_entry__.build()"
+    hdr, push, paths, bufs = read_fixture(FIXTURE)
+    assert not paths
+    src = load_shader_source(SHADER_TEMPLATE.format(refraction=hdr["refraction_mode"], emission=hdr["use_emission"],
+                                                    early_t=hdr["early_t_break"]), hdr["order"], [])
+    src_path, img_path = tmp_path / "shader.glsl", tmp_path / "image.f32"
+    src_path.write_text(src.source_compute)
+    run = subprocess.run([harness, FIXTURE, str(src_path), str(img_path)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    w, h = hdr["width"], hdr["height"]
+    gpu = np.fromfile(img_path, np.float32).reshape(h, w, 4)
+    wd = pta.work_dispatcher
+    packed = wd.PackedScene(materials=bufs[(2, 0)], spheres=bufs[(2, 1)], planes=bufs[(2, 2)], triangles=bufs[(2, 3)],
+                            bvh=bufs[(3, 0)], object_ids=bufs[(3, 1)], transforms=bufs[(6, 0)], proc_tex_paths=paths,
+                            sampled_textures=[], bvh_order=hdr["order"])
+    cpu = np.zeros((h, w, 4), np.float32)
+    ob.render(packed, push, cpu, hdr["groups_x"], hdr["groups_y"], trace=False)
+    assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32)), "the RD core harness's image differs from the oracle"
+
+
 def display_restatement(img, transfer):
     """numpy form of ptk_image_read_display: clamp, canvas.gdshader's pow(rgb, 2.2), sRGB encode, round to 8 bits."""
     v = np.nan_to_num(img.astype(np.float64), nan=0.0).clip(0.0, 1.0)

@@ -104,6 +104,66 @@ def test_library_exports_every_declared_symbol(pta):
     assert not missing, f"libptk.so lacks {missing}"
 
 
+def test_shader_source_is_read_not_compiled(pta):
+    """ptk_shader_source_info (no context, no GPU): the order constant, the three switches and the spliced
+    procedural-texture functions of an edited shader text; a file's digest is the same on disk and spliced in."""
+    import ctypes as C
+    from godot_style_dispatcher import CHECKER_XYZ, CHECKER_XZ, SHADER_TEMPLATE, load_shader_source
+    lib = pta.load_library()
+    info = (C.c_int32 * 21)()
+    src = load_shader_source(SHADER_TEMPLATE.format(refraction=1, emission=1, early_t=0), 8, [CHECKER_XZ, CHECKER_XYZ]).source_compute.encode()
+    assert lib.ptk_shader_source_info(None, src, len(src), info) == 0
+    assert list(info)[:5] == [8, 1, 1, 0, 2] and list(info)[5:7] == [0, 0]  # own files: not the shipped ones
+    assert lib.ptk_shader_source_info(None, b"void main() {}", 14, info) == -1
+    assert b"order" in lib.ptk_last_error(None)
+    d = [C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)]
+    a = CHECKER_XZ.encode()
+    b = ("// a comment\n" + CHECKER_XZ.replace("    ", "\t") + "\n\n").encode()  # comments and white space do not count
+    c = CHECKER_XZ.replace("2.0", "3.0").encode()
+    for text, out in ((a, d[0]), (b, d[1]), (c, d[2])):
+        assert lib.ptk_procedural_texture_digest(text, len(text), C.byref(out)) == 0
+    assert d[0].value == d[1].value != d[2].value
+    assert lib.ptk_procedural_texture_digest(b"float f() { return 1.; }", 24, C.byref(d[0])) == -1
+
+
+def test_plugin_shader_text_is_recognised(pta):
+    """The plugin's own shader and procedural-texture files, edited as PTUtils.load_shader edits them
+    (pt_utils.gd:140-195), read by ptk_shader_source_info: order, default switches, both shipped functions.
+    Needs the plugin checkout (absent on the GPU box)."""
+    import ctypes as C
+    from godot_style_dispatcher import load_shader_source
+    ref = os.environ.get("PTK_PLUGIN_CHECKOUT", "/root/reference")
+    shader = os.path.join(ref, "shaders", "ray_tracer.comp")
+    if not os.path.exists(shader):
+        pytest.skip("no plugin checkout here")
+    texts = [open(os.path.join(ref, "shaders", "procedural_textures", n)).read()
+             for n in ("checker_board.comp", "checker_board_spatial.comp", "checker_board.comp")]
+    src = load_shader_source(open(shader).read(), 8, texts).source_compute.encode()
+    info = (C.c_int32 * 21)()
+    assert pta.load_library().ptk_shader_source_info(None, src, len(src), info) == 0
+    assert list(info)[:8] == [8, 2, 0, 0, 3, 1, 2, 1]
+
+
+def test_godot_facade_answers_every_call_the_plugin_makes():
+    """Every RenderingDevice method named in pt_work_dispatcher.gd / pt_renderer.gd exists on the facade with
+    Godot's parameter names."""
+    import inspect
+    grd = importlib.import_module("path-tracer_amd.godot_rd")
+    calls = {"sampler_create": ["state"], "texture_create": ["format", "view", "data"],
+             "uniform_set_create": ["uniforms", "shader", "shader_set"],
+             "shader_compile_spirv_from_source": ["shader_source", "allow_cache"],
+             "shader_create_from_spirv": ["spirv_data", "name"], "compute_pipeline_create": ["shader", "specialization_constants"],
+             "free_rid": ["rid"], "compute_list_begin": [], "compute_list_bind_compute_pipeline": ["compute_list", "compute_pipeline"],
+             "compute_list_bind_uniform_set": ["compute_list", "uniform_set", "set_index"],
+             "compute_list_set_push_constant": ["compute_list", "buffer", "size_bytes"],
+             "compute_list_dispatch": ["compute_list", "x_groups", "y_groups", "z_groups"], "compute_list_end": [],
+             "submit": [], "sync": [], "storage_buffer_create": ["size_bytes", "data", "usage"],
+             "buffer_update": ["buffer", "offset", "size_bytes", "data"], "texture_get_data": ["texture", "layer"]}
+    for name, params in calls.items():
+        sig = inspect.signature(getattr(grd.RenderingDevice, name))
+        assert list(sig.parameters)[1:] == params, name
+
+
 def test_fails_loudly_without_library():
     """No CPU fallback: a missing libptk.so is an error at first use, naming the path."""
     code = ("import importlib, sys; sys.path.insert(0, %r); p = importlib.import_module('path-tracer_amd');\n"
