@@ -96,6 +96,50 @@ def counter_passes(workload):
     return t, None
 
 
+LIGHT_CONFIGS = [  # label, fixture scene, width, height, depth, refraction bounces, USE_EMISSION
+    ("C1 sphere_scene1", "sphere_scene1", 640, 360, 4, 4, False),
+    ("C2 benchmark_random_scene", "benchmark_random_scene", 1920, 1080, 8, 4, False),
+    ("C3 fake_cornell_box (emission)", "fake_cornell_box", 1920, 1080, 8, 8, True),
+    ("C3 sphere_scene3", "sphere_scene3", 1920, 1080, 8, 8, False),
+    ("C4 dragon_test", "dragon_test", 1920, 1080, 8, 4, False),
+]
+
+
+def light_configs(pta, rd):
+    """Kernel time per sample (median of 8 dispatches, HIP events) and rays per sample (one traced dispatch) of the
+    BASELINE configurations other than the headline one, rendered the way a host gets them: renderer AUTO."""
+    wd = pta.work_dispatcher
+    RD = pta.rendering_device
+    names = {RD.PTK_RENDERER_SINGLE_KERNEL: "single_kernel", RD.PTK_RENDERER_WAVEFRONT: "wavefront", RD.PTK_RENDERER_PERSISTENT: "persistent"}
+    rows = []
+    for label, name, w, h, depth, bounces, emission in LIGHT_CONFIGS:
+        scene = pta.scenes.load_fixture_scene(name, os.path.join(ROOT, "tests", "golden"))
+        disp = wd.PTWorkDispatcher(rd)
+        disp.set_scene(scene)
+        disp.create_buffers(w, h, order=8)
+        disp.load_shader(refraction_mode=2, use_emission=emission, early_t_break=False)
+        win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=depth, max_refraction_bounces=bounces)
+        rd.set_renderer(RD.PTK_RENDERER_AUTO)
+        rd.trace_enable(RD.PTK_TRACE_COUNTERS)
+        win.frame = 2
+        disp.create_compute_list(win, scene.camera, wd.sample_time(2), sync=True)
+        rays = int(rd.trace_read_counters(disp.image_buffer).reshape(-1, RD.PTK_NCOUNTERS).sum(0)[RD.COUNTER_NAMES.index("rays")])
+        rd.trace_enable(0)
+        for k in range(10):  # AUTO's probes (two per schedule) and a few settled dispatches
+            win.frame = k
+            disp.create_compute_list(win, scene.camera, wd.sample_time(2))
+        for k in range(8):
+            win.frame = k
+            disp.create_compute_list(win, scene.camera, wd.sample_time(2))
+        rd.sync()
+        ms = float(np.median(rd.dispatch_history_ms(8)))
+        rows.append({"config": label, "width": w, "height": h, "max_ray_depth": depth, "rays_per_sample": rays,
+                     "ms_per_sample": ms, "mrays_per_s": rays / ms / 1e3, "renderer": names.get(rd.last_dispatch_renderer(), "?")})
+        disp.free_rids()
+    rd.set_renderer(RD.PTK_RENDERER_WAVEFRONT)
+    return rows
+
+
 def reference_runtime_note():
     """The shader itself could only be timed by Godot 4.3 on a CPU Vulkan driver (lavapipe); say whether
     this host has them (it never runs them: the oracle is the baseline that is timed)."""
@@ -116,6 +160,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
     ap.add_argument("--c-abi-comm", action="store_true",
                     help="N > 1: after the timed region, repeat the batch with the reduce done by libptk's own RCCL calls (field c_abi_comm)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the table of the lighter BASELINE configurations (field configs)")
     ap.add_argument("--sah-tree", action="store_true", help="after the timed region, also time the same frames over the binned-SAH tree (field sah_tree)")
     args = ap.parse_args()
 
@@ -479,6 +524,14 @@ def main():
         finally:
             for m in scene.meshes:
                 m.bvh_type = pta.scene.BVH_XYZ_SORTED
+
+    if world == 1 and not args.no_configs:
+        # Beside the contract's figure: the lighter BASELINE configurations (C1-C4), each on the schedule the library
+        # picks by itself (AUTO times the three schedules on a workload's first dispatches and keeps the fastest).
+        try:
+            out["configs"] = light_configs(pta, rd)
+        except Exception as exc:  # noqa: BLE001
+            out["configs"] = {"error": repr(exc)}
 
     if not args.no_cpu_baseline and world == 1:
         # CPU baseline: the oracle (a restatement of ray_tracer.comp, not Godot/lavapipe, which do not

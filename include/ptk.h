@@ -278,6 +278,9 @@ int ptk_dispatch_history_ms(ptk_ctx* ctx, float* ms, int n);
  * WAVEFRONT / PERSISTENT make ptk_dispatch fail with PTK_E_UNSUPPORTED where they do not apply. */
 enum { PTK_RENDERER_AUTO = 0, PTK_RENDERER_SINGLE_KERNEL = 1, PTK_RENDERER_WAVEFRONT = 2, PTK_RENDERER_PERSISTENT = 3 };
 int ptk_set_renderer(ptk_ctx* ctx, int renderer);
+/* Which of the three schedules rendered the last dispatch (one of PTK_RENDERER_SINGLE_KERNEL / _WAVEFRONT /
+ * _PERSISTENT): what AUTO settled on, once its probing dispatches are over.  No counterpart in the reference. */
+int ptk_last_dispatch_renderer(ptk_ctx* ctx, int* renderer);
 /* Durations (ms) of the traversal-kernel launches of the dispatch `back` calls ago (0 = the last
  * one), from HIP events on the context's stream.  *n_launches = number of launches (0 when that
  * dispatch used another renderer); ms needs room for that many.  A dispatch issued with
@@ -315,6 +318,13 @@ int ptk_comm_init(ptk_ctx* ctx, int world, int rank, const void* id128);
 int ptk_image_reduce_mean(ptk_ctx* ctx, uint64_t image, int root);
 int ptk_image_gather_bands(ptk_ctx* ctx, uint64_t image, const int32_t* first_row, const int32_t* n_rows, int root);
 int ptk_comm_destroy(ptk_ctx* ctx);
+/* The band tables for ptk_image_gather_bands (and for the image_offset_y / group counts each rank dispatches with):
+ * the image's 8-row tiles dealt out in rank order, contiguous, tile counts differing by at most one; a rank may get
+ * no rows when there are more ranks than tile rows.  ptk_band_check is the test ptk_image_gather_bands applies to
+ * tables made elsewhere: every band inside the image, no two overlapping (PTK_E_INVALID otherwise, message in
+ * ptk_last_error(NULL)).  Both are plain arithmetic: no context, no GPU. */
+int ptk_band_layout(int image_height, int world, int32_t* first_row, int32_t* n_rows);
+int ptk_band_check(int image_height, int world, const int32_t* first_row, const int32_t* n_rows);
 
 #ifdef __cplusplus
 }

@@ -87,6 +87,7 @@ struct ptk_ctx {
     size_t spill_ints = 0;
     // wavefront renderer
     int renderer = PTK_RENDERER_AUTO;
+    int last_choice = -1;          // schedule of the last dispatch: 0 one-kernel renderer, 1 pipeline, 2 persistent kernel
     bool wf_ok = false;            // scene has no mesh socket below another mesh socket
     float4* d_blocks = nullptr;    // compiled inner nodes, 256 bytes each (see PtkWavefront)
     int2* d_sockets = nullptr;
@@ -1338,6 +1339,7 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         }
     }
 
+    ctx->last_choice = choice;
     if (choice == 0) {
         ctx->wf_iters[slot] = 0;
         HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
@@ -1511,6 +1513,7 @@ int ptk_dispatch_noalloc(ptk_ctx* ctx, const void* push128, int groups_x, int gr
     P.wf.tiles_x = groups_x;
     const int slot = (int)(ctx->dispatch_count % ptk_ctx::kTimingRing);
     ctx->wf_iters[slot] = 0;
+    ctx->last_choice = 2;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
     HIP_TRY(ctx, ptk_launch_persistent(&P, pp_lds, (int)n_wgs, ctx->pp_wg_waves, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
@@ -1559,6 +1562,13 @@ int ptk_set_renderer(ptk_ctx* ctx, int renderer) {
         renderer != PTK_RENDERER_PERSISTENT)
         return fail(ctx, PTK_E_INVALID, "unknown renderer %d", renderer);
     ctx->renderer = renderer;
+    return PTK_OK;
+}
+
+int ptk_last_dispatch_renderer(ptk_ctx* ctx, int* renderer) {
+    if (!ctx || !renderer) return PTK_E_INVALID;
+    if (ctx->last_choice < 0) return fail(ctx, PTK_E_STATE, "no dispatch has run");
+    *renderer = ctx->last_choice == 0 ? PTK_RENDERER_SINGLE_KERNEL : ctx->last_choice == 1 ? PTK_RENDERER_WAVEFRONT : PTK_RENDERER_PERSISTENT;
     return PTK_OK;
 }
 
@@ -1925,15 +1935,44 @@ int ptk_image_reduce_mean(ptk_ctx* ctx, uint64_t image, int root) {
     return PTK_OK;
 }
 
+int ptk_band_layout(int image_height, int world, int32_t* first_row, int32_t* n_rows) {
+    if (image_height <= 0 || world <= 0 || !first_row || !n_rows) return PTK_E_INVALID;
+    // contiguous bands of 8-row tiles whose tile counts differ by at most one; the last tile row may be cut by the image
+    const int tiles = (image_height + 7) / 8, base = tiles / world, extra = tiles % world;
+    int start = 0;
+    for (int r = 0; r < world; r++) {
+        const int n = base + (r < extra ? 1 : 0);
+        first_row[r] = std::min(start * 8, image_height);
+        n_rows[r] = std::max(0, std::min(n * 8, image_height - start * 8));
+        start += n;
+    }
+    return PTK_OK;
+}
+
+// Bands as ptk_image_gather_bands accepts them: inside the image and disjoint (rank order is free).
+static int check_bands(ptk_ctx* ctx, int height, int world, const int32_t* first_row, const int32_t* n_rows) {
+    for (int k = 0; k < world; k++)
+        if (first_row[k] < 0 || n_rows[k] < 0 || (long long)first_row[k] + n_rows[k] > height)
+            return fail(ctx, PTK_E_INVALID, "band of rank %d (rows %d..%d) leaves the image (%d rows)", k, first_row[k], first_row[k] + n_rows[k], height);
+    for (int a = 0; a < world; a++)
+        for (int b = a + 1; b < world; b++)
+            if (n_rows[a] > 0 && n_rows[b] > 0 && first_row[a] < first_row[b] + n_rows[b] && first_row[b] < first_row[a] + n_rows[a])
+                return fail(ctx, PTK_E_INVALID, "bands of ranks %d and %d overlap", a, b);
+    return PTK_OK;
+}
+
+int ptk_band_check(int image_height, int world, const int32_t* first_row, const int32_t* n_rows) {
+    if (image_height <= 0 || world <= 0 || !first_row || !n_rows) return PTK_E_INVALID;
+    return check_bands(nullptr, image_height, world, first_row, n_rows);
+}
+
 int ptk_image_gather_bands(ptk_ctx* ctx, uint64_t image, const int32_t* first_row, const int32_t* n_rows, int root) {
     if (!ctx) return PTK_E_INVALID;
     if (!ctx->comm) return fail(ctx, PTK_E_STATE, "ptk_comm_init has not been called");
     Object* o = find(ctx, image, Kind::Image);
     if (!o) return fail(ctx, PTK_E_INVALID, "unknown image handle");
     if (!first_row || !n_rows || root < 0 || root >= ctx->comm_world) return fail(ctx, PTK_E_INVALID, "band tables and a root inside the communicator are required");
-    for (int k = 0; k < ctx->comm_world; k++)
-        if (first_row[k] < 0 || n_rows[k] < 0 || (long long)first_row[k] + n_rows[k] > o->height)
-            return fail(ctx, PTK_E_INVALID, "band of rank %d (rows %d..%d) leaves the image (%d rows)", k, first_row[k], first_row[k] + n_rows[k], o->height);
+    { int r = check_bands(ctx, o->height, ctx->comm_world, first_row, n_rows); if (r != PTK_OK) return r; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc = flush_updates(ctx)) return rc;
     Rccl& r = rccl();

@@ -34,7 +34,8 @@ EXPORTS = [
     "ptk_image_read_display", "ptk_mesh_to_triangles", "ptk_set_option",
     "ptk_bvh_bind", "ptk_bvh_refit",
     "ptk_buffer_bind", "ptk_texture_bind", "ptk_configure_from_source", "ptk_shader_source_info",
-    "ptk_register_procedural_texture", "ptk_procedural_texture_digest",
+    "ptk_register_procedural_texture", "ptk_procedural_texture_digest", "ptk_last_dispatch_renderer",
+    "ptk_band_layout", "ptk_band_check",
 ]
 
 PTK_RENDERER_AUTO, PTK_RENDERER_SINGLE_KERNEL, PTK_RENDERER_WAVEFRONT, PTK_RENDERER_PERSISTENT = 0, 1, 2, 3
@@ -150,12 +151,18 @@ def load_library() -> C.CDLL:
     lib.ptk_image_reduce_mean.argtypes = [vp, u64, C.c_int]
     lib.ptk_image_gather_bands.restype = C.c_int
     lib.ptk_image_gather_bands.argtypes = [vp, u64, vp, vp, C.c_int]
+    lib.ptk_band_layout.restype = C.c_int
+    lib.ptk_band_layout.argtypes = [C.c_int, C.c_int, i32p, i32p]
+    lib.ptk_band_check.restype = C.c_int
+    lib.ptk_band_check.argtypes = [C.c_int, C.c_int, i32p, i32p]
     lib.ptk_comm_destroy.restype = C.c_int
     lib.ptk_comm_destroy.argtypes = [vp]
     lib.ptk_update_stats.restype = C.c_int
     lib.ptk_update_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     lib.ptk_set_renderer.restype = C.c_int
     lib.ptk_set_renderer.argtypes = [vp, C.c_int]
+    lib.ptk_last_dispatch_renderer.restype = C.c_int
+    lib.ptk_last_dispatch_renderer.argtypes = [vp, C.POINTER(C.c_int)]
     lib.ptk_dispatch_traverse_ms.restype = C.c_int
     lib.ptk_dispatch_traverse_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     _lib = lib
@@ -435,6 +442,12 @@ class PtkRenderingDevice:
     def set_renderer(self, renderer: int):
         """PTK_RENDERER_AUTO / _SINGLE_KERNEL / _WAVEFRONT / _PERSISTENT: the schedule used for the next dispatches."""
         self._check(self.lib.ptk_set_renderer(self.ctx, int(renderer)), "ptk_set_renderer")
+
+    def last_dispatch_renderer(self) -> int:
+        """PTK_RENDERER_* of the schedule that rendered the last dispatch."""
+        r = C.c_int(0)
+        self._check(self.lib.ptk_last_dispatch_renderer(self.ctx, C.byref(r)), "ptk_last_dispatch_renderer")
+        return int(r.value)
 
     def dispatch_traverse_ms(self, back: int = 0):
         """Durations of the traversal-kernel launches of the dispatch `back` calls ago ([] = another renderer ran;

@@ -196,6 +196,33 @@ def test_row_bands_cover_the_image():
     assert ids == list(range(20))
 
 
+def test_band_tables_of_the_c_abi(pta):
+    """ptk_band_layout / ptk_band_check (the tables ptk_image_gather_bands works from), worlds of 2 and 8, heights
+    whose tile rows do not divide evenly or are cut by the image, more ranks than tile rows; and the faults the check
+    must name.  Plain arithmetic: no context, no communicator."""
+    import ctypes as C
+    mg = importlib.import_module("path-tracer_amd.multi_gpu")
+    lib = pta.load_library()
+    for height, world in [(1080, 2), (1080, 8), (2160, 8), (100, 3), (8, 4), (1084, 8), (7, 2)]:
+        first, rows = (C.c_int32 * world)(), (C.c_int32 * world)()
+        assert lib.ptk_band_layout(height, world, first, rows) == 0
+        assert lib.ptk_band_check(height, world, first, rows) == 0
+        tiles = (height + 7) // 8
+        expect = mg.row_bands(tiles, world)
+        assert [f // 8 for f, r in zip(first, rows) if r] == [f for f, n in expect if n] and all(f % 8 == 0 for f, r in zip(first, rows) if r)
+        assert [(-(-r // 8)) for r in rows] == [n for _, n in expect]
+        assert sum(rows) == height and first[0] == 0
+        covered = np.zeros(height, np.int32)
+        for f, r in zip(first, rows):
+            covered[f:f + r] += 1
+        assert (covered == 1).all()
+    first, rows = (C.c_int32 * 2)(0, 536), (C.c_int32 * 2)(544, 544)
+    assert lib.ptk_band_check(1080, 2, first, rows) == -1 and b"overlap" in lib.ptk_last_error(None)
+    first, rows = (C.c_int32 * 2)(0, 544), (C.c_int32 * 2)(544, 544)
+    assert lib.ptk_band_check(1080, 2, first, rows) == -1 and b"leaves the image" in lib.ptk_last_error(None)
+    assert lib.ptk_band_layout(1080, 0, first, rows) == -1
+
+
 def test_two_rank_partitioning_matches_one_rank(tmp_path):
     """World size 2 over gloo: tile rows assemble to the one-rank image bit for bit; sample batches
     (numbered from frame 1) average to the mean of all samples of all ranks (summation order differs from a

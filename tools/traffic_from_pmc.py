@@ -6,6 +6,8 @@ the kernel: busy cycles summed over the 256 compute units against the launch's c
 over the 8 XCDs)."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # kernel_source_hash: the stamp bench.py checks before it reports these figures as its own
 src, kept_as = sys.argv[1], sys.argv[2]
 r = json.load(open(src))
 m = lambda g, k: r[g][k]["mean_per_dispatch"]
@@ -15,6 +17,7 @@ fetch_kb, write_kb = m("F", "FETCH_SIZE"), m("W", "WRITE_SIZE")
 old = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
 out = {
     "workload": old["workload"],
+    "source_hash": bench.kernel_source_hash(),
     "kernel": "ptk_wf_traverse",
     "command": old["command"],
     "launches_averaged": r["F"]["FETCH_SIZE"]["dispatches"],
@@ -26,6 +29,9 @@ out = {
     "limiter": {
         "what": old["limiter"]["what"],
         "valu_busy": m("A", "SQ_ACTIVE_INST_VALU") / (cycles * n_cu),
+        # share of the 64 lanes an issued VALU instruction works for (group L: both counters from one pass)
+        "lane_fraction": (m("L", "SQ_THREAD_CYCLES_VALU") / (m("L", "SQ_ACTIVE_INST_VALU") * 64.0)) if "L" in r and "SQ_THREAD_CYCLES_VALU" in r["L"] else None,
+        "valu_insts_per_launch": m("A", "SQ_INSTS_VALU"),
         "ta_busy": m("B", "TA_TA_BUSY_sum") / (cycles * n_cu),
         "td_busy": m("B", "TD_TD_BUSY_sum") / (cycles * n_cu),
         "cycles_per_launch": cycles,
