@@ -125,9 +125,9 @@ def light_configs(pta, rd):
         disp.create_compute_list(win, scene.camera, wd.sample_time(2), sync=True)
         rays = int(rd.trace_read_counters(disp.image_buffer).reshape(-1, RD.PTK_NCOUNTERS).sum(0)[RD.COUNTER_NAMES.index("rays")])
         rd.trace_enable(0)
-        for k in range(10):  # AUTO's probes (two per schedule) and a few settled dispatches
+        for k in range(10):  # AUTO's probes (two per schedule, read back once their events have completed) and a few settled dispatches
             win.frame = k
-            disp.create_compute_list(win, scene.camera, wd.sample_time(2))
+            disp.create_compute_list(win, scene.camera, wd.sample_time(2), sync=True)
         for k in range(8):
             win.frame = k
             disp.create_compute_list(win, scene.camera, wd.sample_time(2))

@@ -769,11 +769,18 @@ PTK_DEV bool trav_inner(const PtkParams& P, const Stack& S, Trav& T) {
             start = __builtin_fmaxf(start, nz ? scz[e] : t0z[e]);
             end = __builtin_fminf(end, nz ? sbz[e] : t1z[e]);
             const bool acc = (l < node_size) && (end > start) && range_ok;
+#ifdef PTK_INNER_V1
             key[l] = acc ? (fbits(start) & 0x7FFFFFFFu) : 0x7F800000u;
+#else
+            // key of an accepted child: the bits of its entry distance t (t >= 0, so unsigned order is float order) with
+            // the top bit set -- which also makes -0 and +0 one key; a rejected child's key is 0, below every accepted one
+            key[l] = acc ? (fbits(start) | 0x80000000u) : 0u;
+#endif
             ent[l] = fbits(en[e]);
             added += acc ? 1 : 0;
         }
     }
+#ifdef PTK_INNER_V1
     // rank = number of children the shader's selection loop (:1157-1178) would take earlier: smaller t, or
     // equal t in a lower slot.  For j < l, u = 1 iff child l is strictly nearer than child j (sign bit of
     // key[l] - key[j]; both keys < 2^31): rank[l] = l - sum_{j<l} u(j,l) + sum_{m>l} u(l,m).
@@ -810,6 +817,42 @@ PTK_DEV bool trav_inner(const PtkParams& P, const Stack& S, Trav& T) {
             }
         }
     }
+#else
+    // The shader's selection loop (:1157-1178) takes the accepted children in order of t, equal t in slot order, and
+    // pushes them so that the first taken ends on top.  Child l therefore sits `above[l]` entries over the old top,
+    // above[l] = how many accepted children are taken after it = #{j < l : key[j] > key[l]} + #{m > l : key[m] >= key[l]}
+    //          = sum_{j<l} u(j,l) + (7 - l) - sum_{m>l} u(l,m)        with u(a,b) = [key[a] > key[b]], a < b.
+    // The same formula sends the rejected children (key 0) to the rows from `added` upwards, each to its own: past
+    // the new top, inside the window when sp + 8 <= lds_cap, where nothing reads them.  So all eight stores go out
+    // unconditionally, and the nearest child is read back from row sp + added - 1.
+    int above[PTK_MAX_WIDTH];
+#pragma unroll
+    for (int l = 0; l < PTK_MAX_WIDTH; l++) above[l] = PTK_MAX_WIDTH - 1 - l;
+#pragma unroll
+    for (int l = 1; l < PTK_MAX_WIDTH; l++) {
+#pragma unroll
+        for (int j = 0; j < l; j++) {
+            const int u = key[j] > key[l] ? 1 : 0;
+            above[l] += u;
+            above[j] -= u;
+        }
+    }
+    cur = ENTRY_NONE;
+    if (sp + PTK_MAX_WIDTH <= S.lds_cap) {
+        int* const row0 = lds_lane + sp * 64;
+#pragma unroll
+        for (int l = 0; l < PTK_MAX_WIDTH; l++) row0[above[l] * 64] = (int)ent[l];
+        if (added > 0) cur = (uint32_t)row0[(added - 1) * 64];
+    } else {
+#pragma unroll
+        for (int l = 0; l < PTK_MAX_WIDTH; l++) {
+            if (key[l] != 0u) {
+                if (above[l] == added - 1) cur = ent[l];
+                else st_write(S, sp + above[l], (int)ent[l]);
+            }
+        }
+    }
+#endif
     T.cur = cur;
     T.sp = sp + ((added > 0) ? added - 1 : 0);
     return added == 0;
