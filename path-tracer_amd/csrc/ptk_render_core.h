@@ -863,6 +863,7 @@ PTK_DEV bool trav_inner(const PtkParams& P, const Stack& S, Trav& T) {
 // {B.xyz | radius, -}, {C.xyz, -}, stored in object-id-slot order.
 PTK_DEV void leaf_span(const PtkParams& P, int first, int count, int cur_xf, Ray& r, Hit& h, bool* either_root) {
     const float4* __restrict__ rec = P.wf.leaf_records + (size_t)first * 3;
+#ifdef PTK_LEAF_NO_PREFETCH
     for (int k = 0;; k++) {
         const bool go = k < count;
         if (__ballot(go) == 0ull) break;
@@ -874,6 +875,34 @@ PTK_DEV void leaf_span(const PtkParams& P, int first, int count, int cur_xf, Ray
             else if (type == IS_SPHERE) hit_sphere_rec(r, h, object_id, cur_xf, ld3(r0), r1.x, either_root);
         }
     }
+#else
+    // Four records at a time: their loads go out together, so the round waits for memory once per four objects
+    // instead of once per object (a split leaf has at most four).  The tests themselves stay in order.
+    constexpr int LEAF_BATCH = 4;
+    for (int k0 = 0;; k0 += LEAF_BATCH) {
+        if (__ballot(k0 < count) == 0ull) break;
+        float4 q[LEAF_BATCH][3];
+#pragma unroll
+        for (int i = 0; i < LEAF_BATCH; i++) {
+            if (k0 + i < count) {
+                q[i][0] = rec[(k0 + i) * 3]; q[i][1] = rec[(k0 + i) * 3 + 1]; q[i][2] = rec[(k0 + i) * 3 + 2];
+            } else {
+                q[i][0] = q[i][1] = q[i][2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LEAF_BATCH; i++) {
+            const bool go = k0 + i < count;
+            if (i > 0 && __ballot(go) == 0ull) break;
+            if (go) {
+                const int object_id = (int)fbits(q[i][0].w);
+                const int type = bfe_i(object_id, 24, 8);
+                if (type == IS_TRIANGLE) hit_triangle_rec(r, h, object_id, cur_xf, ld3(q[i][0]), ld3(q[i][1]), ld3(q[i][2]));
+                else if (type == IS_SPHERE) hit_sphere_rec(r, h, object_id, cur_xf, ld3(q[i][0]), q[i][1].x, either_root);
+            }
+        }
+    }
+#endif
 }
 
 PTK_DEV int wave_rank_in(unsigned long long mask) {  // set bits of mask below this lane

@@ -52,7 +52,9 @@ PTK_DEV int lane_rank_in(unsigned long long mask) {  // set bits of mask below t
 //   [130, 195) lane visits by size of the group of lanes that share the block
 //   [200, 232) lane visits by block depth          [232, 264) distinct block fetches by block depth
 //   [264]      lane visits of mesh sockets         [265] leaf rounds   [266] lanes on a leaf in leaf rounds
-#define PTK_WF_NSTATS 272
+//   [272..274] shader-clock ticks spent in inner / leaf / refill rounds, summed over the waves; [276..278] their numbers
+//   (-DPTK_WF_CLOCKS_ONLY: only these, so that the counting itself does not weigh on the rounds it times)
+#define PTK_WF_NSTATS 280
 __device__ unsigned long long g_wf_stats[PTK_WF_NSTATS];
 namespace {
 PTK_DEV void wf_stats_inner_round(const PtkParams& P, const Trav& T, bool is_inner, unsigned long long mi, int lane) {
@@ -226,7 +228,17 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
     T.w_o = mk3(0, 0, 0); T.w_d = mk3(0, 0, 1); T.w_start = 0.0f; T.dir_len = 1.0f;
 
     bool parked = false;  // this wave has parked its searches (what it could not park it finishes itself)
+#ifdef PTK_WF_STATS
+    long long st_clk[3] = {0, 0, 0};  // shader-clock ticks this wave spent in inner / leaf / refill rounds
+    long long st_n[3] = {0, 0, 0};    // ... and how many of each it ran
+#define PTK_ST_ROUND_END(k) (st_clk[k] += clock64() - st_c0, st_n[k]++)
+#else
+#define PTK_ST_ROUND_END(k)
+#endif
     for (;;) {
+#ifdef PTK_WF_STATS
+        const long long st_c0 = clock64();
+#endif
         const bool is_leaf = have && trav_is_leaf(T);
         const bool is_inner = have && trav_is_inner(T);
         const unsigned long long mi = __ballot(is_inner), ml = __ballot(is_leaf);
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
 
         if ((mi | ml) == 0ull || park_now || (!exhausted && n_idle >= PTK_WF_REFILL)) {
             // ---- refill round: retire finished rays, claim new ones ----
-#ifdef PTK_WF_STATS
+#if defined(PTK_WF_STATS) && !defined(PTK_WF_CLOCKS_ONLY)
             if (lane == 0) atomicAdd(&g_wf_stats[271], 1ull);
 #endif
             if (have && T.cur == ENTRY_NONE) {
@@ -295,6 +307,7 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
                     }
                 }
             }
+            PTK_ST_ROUND_END(2);
             if (exhausted && __ballot(have) == 0ull) {
                 if (!parked && lane == 0) atomicAdd((int*)wg_flags + 1, 1);
                 break;
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
         }
 
         bool pop = false;
-#ifdef PTK_WF_STATS
+#if defined(PTK_WF_STATS) && !defined(PTK_WF_CLOCKS_ONLY)
         if (PTK_WF_VOTE_INNER(__popcll(mi), __popcll(ml))) {
             wf_stats_inner_round(P, T, is_inner, mi, lane);
             if (lane == 0) { atomicAdd(&g_wf_stats[267], (unsigned long long)__popcll(ml)); atomicAdd(&g_wf_stats[268], (unsigned long long)n_idle); }
@@ -319,7 +332,11 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
             pop = is_leaf;
         }
         if (pop) trav_pop(S, T);
+        PTK_ST_ROUND_END(PTK_WF_VOTE_INNER(__popcll(mi), __popcll(ml)) ? 0 : 1);
     }
+#ifdef PTK_WF_STATS
+    if (lane == 0) for (int k = 0; k < 3; k++) { atomicAdd(&g_wf_stats[272 + k], (unsigned long long)st_clk[k]); atomicAdd(&g_wf_stats[276 + k], (unsigned long long)st_n[k]); }
+#endif
 #ifdef PTK_WF_ENDS
     if (lane == 0 && iter < PTK_WF_ENDS_ITERS) g_wf_ends[ends_at + 1] = wall_clock64();
 #endif

@@ -27,16 +27,16 @@ disp.set_scene(scene)
 disp.create_buffers(w, h, order=8)
 disp.load_shader()
 win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=8, max_refraction_bounces=4)
-st = np.zeros(272, np.uint64)
-lib.ptk_dev_wf_stats(rd.ctx, st.ctypes.data, 272)  # clear
+st = np.zeros(280, np.uint64)
+lib.ptk_dev_wf_stats(rd.ctx, st.ctypes.data, 280)  # clear
 win.frame = 1
 disp.create_compute_list(win, scene.camera, wd.sample_time(1), sync=True)
-assert lib.ptk_dev_wf_stats(rd.ctx, st.ctypes.data, 272) == 0
+assert lib.ptk_dev_wf_stats(rd.ctx, st.ctypes.data, 280) == 0
 st = st.astype(np.int64)
 act, dist, grp = st[0:65], st[65:130], st[130:195]
 dv, dd = st[200:232], st[232:264]
-rounds = act.sum()
-lanes = (act * np.arange(65)).sum()
+rounds = max(act.sum(), 1)
+lanes = max((act * np.arange(65)).sum(), 1)
 print("inner rounds", rounds, "lane visits", lanes, "mean lanes per round %.1f" % (lanes / rounds))
 print("inner rounds with at most 16 / 24 / 32 / 40 / 48 lanes: " + " / ".join("%.1f %%" % (100.0 * act[:k + 1].sum() / rounds) for k in (16, 24, 32, 40, 48)))
 print("distinct blocks per round: mean %.1f" % ((dist * np.arange(65)).sum() / rounds), " fetches saved by sharing: %.1f %%" % (100 * (1 - (dist * np.arange(65)).sum() / lanes)))
@@ -47,6 +47,9 @@ print("socket lane visits", st[264], " leaf rounds", st[265], "lanes per leaf ro
 print("inner rounds: lanes waiting at a leaf %.1f, idle %.1f" % (st[267] / rounds, st[268] / rounds))
 print("leaf rounds: lanes waiting at an inner node %.1f, idle %.1f" % (st[269] / max(st[265], 1), st[270] / max(st[265], 1)))
 print("refill rounds", st[271])
+tk, tn = st[272:275].astype(np.float64), np.maximum(st[276:279].astype(np.float64), 1)
+print("wave time by kind of round (shader clock): inner %.1f %%, leaf %.1f %%, refill %.1f %%;  rounds %d / %d / %d;  ticks per round: inner %.0f, leaf %.0f, refill %.0f" % (
+    100 * tk[0] / tk.sum(), 100 * tk[1] / tk.sum(), 100 * tk[2] / tk.sum(), tn[0], tn[1], tn[2], tk[0] / tn[0], tk[1] / tn[1], tk[2] / tn[2]))
 print("| depth | lane visits | share | cumulative | distinct fetches | lanes per fetch |")
 c = 0.0
 for d in range(32):
