@@ -231,27 +231,19 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
 #ifdef PTK_WF_STATS
     long long st_clk[3] = {0, 0, 0};  // shader-clock ticks this wave spent in inner / leaf / refill rounds
     long long st_n[3] = {0, 0, 0};    // ... and how many of each it ran
+#define PTK_ST_ROUND_BEGIN() const long long st_c0 = clock64()
 #define PTK_ST_ROUND_END(k) (st_clk[k] += clock64() - st_c0, st_n[k]++)
 #else
+#define PTK_ST_ROUND_BEGIN()
 #define PTK_ST_ROUND_END(k)
 #endif
+    // Two nested loops: a refill round, then search rounds until the next refill is due.  (Written as one loop with
+    // the refill as a branch, every search round paid some seventy register moves: the refill replaces a lane's whole
+    // search state, and the compiler kept a second copy of that state alive through all the other rounds.)
     for (;;) {
-#ifdef PTK_WF_STATS
-        const long long st_c0 = clock64();
-#endif
-        const bool is_leaf = have && trav_is_leaf(T);
-        const bool is_inner = have && trav_is_inner(T);
-        const unsigned long long mi = __ballot(is_inner), ml = __ballot(is_leaf);
-        const int n_idle = 64 - __popcll(mi | ml);
-        // The queue is dry (this wave found out at a refill, or another wave of the workgroup did) and few searches
-        // are left here, or half of the workgroup's waves are through: time to park what is left
-        // (a wave with part of a claimed chunk left still has rays to hand to its lanes)
-        if (carry_on && !exhausted && c_next == c_end && wg_flags[0] != 0) exhausted = true;
-        const bool park_now = exhausted && carry_on && !parked &&
-                              (64 - n_idle <= W.park_below || wg_flags[1] >= PTK_WF_WG_WAVES / 2);
-
-        if ((mi | ml) == 0ull || park_now || (!exhausted && n_idle >= PTK_WF_REFILL)) {
+        {
             // ---- refill round: retire finished rays, claim new ones ----
+            PTK_ST_ROUND_BEGIN();
 #if defined(PTK_WF_STATS) && !defined(PTK_WF_CLOCKS_ONLY)
             if (lane == 0) atomicAdd(&g_wf_stats[271], 1ull);
 #endif
@@ -312,27 +304,42 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
                 if (!parked && lane == 0) atomicAdd((int*)wg_flags + 1, 1);
                 break;
             }
-            continue;
         }
+        // ---- search rounds until lanes have run out of work (or the wave is to park what it has) ----
+        for (;;) {
+            PTK_ST_ROUND_BEGIN();
+            const bool is_leaf = have && trav_is_leaf(T);
+            const bool is_inner = have && trav_is_inner(T);
+            const unsigned long long mi = __ballot(is_inner), ml = __ballot(is_leaf);
+            const int n_idle = 64 - __popcll(mi | ml);
+            // The queue is dry (this wave found out at a refill, or another wave of the workgroup did) and few searches
+            // are left here, or half of the workgroup's waves are through: time to park what is left
+            // (a wave with part of a claimed chunk left still has rays to hand to its lanes)
+            if (carry_on && !exhausted && c_next == c_end && wg_flags[0] != 0) exhausted = true;
+            const bool park_now = exhausted && carry_on && !parked &&
+                                  (64 - n_idle <= W.park_below || wg_flags[1] >= PTK_WF_WG_WAVES / 2);
+            if ((mi | ml) == 0ull || park_now || (!exhausted && n_idle >= PTK_WF_REFILL)) break;
 
-        bool pop = false;
+            const bool inner_round = PTK_WF_VOTE_INNER(__popcll(mi), __popcll(ml));
 #if defined(PTK_WF_STATS) && !defined(PTK_WF_CLOCKS_ONLY)
-        if (PTK_WF_VOTE_INNER(__popcll(mi), __popcll(ml))) {
-            wf_stats_inner_round(P, T, is_inner, mi, lane);
-            if (lane == 0) { atomicAdd(&g_wf_stats[267], (unsigned long long)__popcll(ml)); atomicAdd(&g_wf_stats[268], (unsigned long long)n_idle); }
-        } else if (lane == 0) {
-            atomicAdd(&g_wf_stats[265], 1ull); atomicAdd(&g_wf_stats[266], (unsigned long long)__popcll(ml));
-            atomicAdd(&g_wf_stats[269], (unsigned long long)__popcll(mi)); atomicAdd(&g_wf_stats[270], (unsigned long long)n_idle);
-        }
+            if (inner_round) {
+                wf_stats_inner_round(P, T, is_inner, mi, lane);
+                if (lane == 0) { atomicAdd(&g_wf_stats[267], (unsigned long long)__popcll(ml)); atomicAdd(&g_wf_stats[268], (unsigned long long)n_idle); }
+            } else if (lane == 0) {
+                atomicAdd(&g_wf_stats[265], 1ull); atomicAdd(&g_wf_stats[266], (unsigned long long)__popcll(ml));
+                atomicAdd(&g_wf_stats[269], (unsigned long long)__popcll(mi)); atomicAdd(&g_wf_stats[270], (unsigned long long)n_idle);
+            }
 #endif
-        if (PTK_WF_VOTE_INNER(__popcll(mi), __popcll(ml))) {
-            if (is_inner) pop = trav_inner(P, S, T);  // ---- inner round ----
-        } else {
-            trav_leaf(P, S, T, is_leaf);                 // ---- leaf round ----
-            pop = is_leaf;
+            bool pop = false;
+            if (inner_round) {
+                if (is_inner) pop = trav_inner(P, S, T);  // ---- inner round ----
+            } else {
+                trav_leaf(P, S, T, is_leaf);                 // ---- leaf round ----
+                pop = is_leaf;
+            }
+            if (pop) trav_pop(S, T);
+            PTK_ST_ROUND_END(inner_round ? 0 : 1);
         }
-        if (pop) trav_pop(S, T);
-        PTK_ST_ROUND_END(PTK_WF_VOTE_INNER(__popcll(mi), __popcll(ml)) ? 0 : 1);
     }
 #ifdef PTK_WF_STATS
     if (lane == 0) for (int k = 0; k < 3; k++) { atomicAdd(&g_wf_stats[272 + k], (unsigned long long)st_clk[k]); atomicAdd(&g_wf_stats[276 + k], (unsigned long long)st_n[k]); }
