@@ -758,7 +758,8 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
         last = std::min(last, o->nbytes / rec_bytes);
     };
     if (o->set == PTK_SET_OBJECT && o->binding == 0) return 1;  // materials: nothing is derived from their contents
-    if (o->set == PTK_SET_TRANSFORM || o->set == PTK_SET_TRIANGLE || o->set == PTK_SET_TEXTURE) return 1;
+    if (o->set == PTK_SET_TRANSFORM) { derive_chain(ctx); return 1; }  // (a chain step holds its matrix by value)
+    if (o->set == PTK_SET_TRIANGLE || o->set == PTK_SET_TEXTURE) return 1;
     if (o->set == PTK_SET_OBJECT && o->binding == 2) {  // planes
         size_t a, b;
         records(32, a, b);
@@ -844,6 +845,9 @@ static void derive_chain(ptk_ctx* ctx) {
                 memset(&c, 0, sizeof c);
                 c.kind = 1;
                 c.xf = ctx->h_sockets[si * 2 + 1];
+                Object* xfb = bound_buffer(ctx, PTK_SET_TRANSFORM, 0);
+                if (!xfb || c.xf < 0 || ((size_t)c.xf + 1) * 64 > xfb->shadow.size()) break;  // (validation has checked the index)
+                memcpy(c.m, xfb->shadow.data() + (size_t)c.xf * 64, 64);
                 e = (uint32_t)ctx->h_sockets[si * 2];
             } else if ((int32_t)e > 0 && (e >> 24) == 1u) {  // inner node with one child
                 const size_t b = e & 0x00FFFFFFu;
@@ -1168,6 +1172,14 @@ static int fill_params(ptk_ctx* ctx, const void* push128, PtkParams& P) {
     P.transforms = (const float4*)xf->dev;
     P.live_planes = ctx->d_live_planes;
     P.n_live_planes = ctx->n_live_planes;
+    P.n_arg_planes = -1;
+    if (ctx->h_live_planes.size() <= PTK_ARG_PLANES) {
+        P.n_arg_planes = (int)ctx->h_live_planes.size();
+        for (int i = 0; i < P.n_arg_planes; i++) {
+            P.arg_plane_index[i] = ctx->h_live_planes[(size_t)i];
+            memcpy(&P.arg_plane[i], pln->shadow.data() + (size_t)ctx->h_live_planes[(size_t)i] * 32, 16);
+        }
+    }
     P.n_spheres = (int)(sph->nbytes / 32);
     P.n_planes = (int)(pln->nbytes / 32);
     P.n_triangles = (int)(tri->nbytes / 80);

@@ -58,7 +58,13 @@ struct PtkChainStep {
     float lo[3], hi[3];   // kind 0: the child's box (min - pad, max + pad as stored in the node buffer)
     int32_t kind;         // 0 box test, 1 mesh socket
     int32_t xf;           // kind 1: transform index
+    float m[16];          // kind 1: that transform's matrix by value (the 64 bytes of the transform buffer's record),
+                          // so that a search's start waits for no load of it
 };
+// Plane records travel as kernel arguments too when the scene has at most this many that can be hit (a plane whose
+// normal is zero never is): every search tests them first (ray_tracer.comp:1204), and as arguments they cost its
+// start neither the load of the list nor the loads of the records.
+#define PTK_ARG_PLANES 4
 struct PtkWavefront {
     float4* rays[2];
     int4* hits;
@@ -114,6 +120,9 @@ struct PtkParams {
     int n_triangle_uvs;
     const int* live_planes;    // indices of plane records with a non-zero normal
     int n_live_planes;
+    int n_arg_planes;          // >= 0: the live planes are arg_plane[0 .. n_arg_planes) below; -1: read the list
+    int arg_plane_index[PTK_ARG_PLANES];
+    float4 arg_plane[PTK_ARG_PLANES];  // {normal.xyz, distance}: the first 16 bytes of the plane's record
     int n_spheres, n_planes, n_triangles;  // buffer lengths (records), brute-force mode only
     float4* image;
     int img_w, img_h;

@@ -206,14 +206,27 @@ PTK_DEV void hit_triangle_mt(const PtkParams& P, Ray& ray, Hit& h, int object_id
     hit_triangle_rec(ray, h, object_id, cur_xf, ld3(t[0]), ld3(t[1]), ld3(t[2]));
 }
 
-PTK_DEV void hit_plane(const PtkParams& P, Ray& ray, Hit& h, int index, int cur_xf) {  // :851-875
-    float4 pl = P.planes[(size_t)index * 2];
+PTK_DEV void hit_plane_rec(Ray& ray, Hit& h, int index, int cur_xf, float4 pl) {  // :851-875
     f3 n = ld3(pl);
     float t = (pl.w - dot3(ray.o, n)) / dot3(n, ray.d);
     if (t != t || pabs(t) == PT_INF) return;
     if (!in_range(t, ray.start, ray.end)) return;
     h.hit = 1; h.object_id = index + (IS_PLANE << 24); h.transform_index = cur_xf;
     ray.end = t;
+}
+PTK_DEV void hit_plane(const PtkParams& P, Ray& ray, Hit& h, int index, int cur_xf) {
+    hit_plane_rec(ray, h, index, cur_xf, P.planes[(size_t)index * 2]);
+}
+// The planes that can be hit, in index order, before anything else of a search (:1204): from the kernel's arguments
+// when they fit there, else through the list in memory.
+PTK_DEV void hit_live_planes(const PtkParams& P, Ray& ray, Hit& h) {
+    if (P.n_arg_planes >= 0) {
+#pragma unroll
+        for (int i = 0; i < PTK_ARG_PLANES; ++i)
+            if (i < P.n_arg_planes) hit_plane_rec(ray, h, P.arg_plane_index[i], -1, P.arg_plane[i]);
+    } else {
+        for (int i = 0; i < P.n_live_planes; ++i) hit_plane(P, ray, h, P.live_planes[i], -1);
+    }
 }
 
 template <bool TRACE>
@@ -301,7 +314,7 @@ PTK_DEV Hit check_ray_hit_bvh(const PtkParams& P, Lane& L, Ray& ray, const Stack
     // planes are tested first, outside the BVH (:1204).  Records whose normal is
     // exactly zero always yield NaN or Inf and are rejected at :859, so only the
     // others are listed in live_planes (ascending index).
-    for (int i = 0; i < P.n_live_planes; ++i) hit_plane(P, ray, h, P.live_planes[i], -1);
+    hit_live_planes(P, ray, h);
 
     f3 inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     int neg = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
@@ -477,7 +490,7 @@ template <bool TRACE>
 PTK_DEV Hit check_ray_hit_bvh2(const PtkParams& P, Lane& L, Ray& ray, const Stack& S, int* cnt) {
     Hit h;
     h.hit = 0; h.object_id = 0; h.transform_index = -1; h.u = 0.0f; h.v = 0.0f;
-    for (int i = 0; i < P.n_live_planes; ++i) hit_plane(P, ray, h, P.live_planes[i], -1);
+    hit_live_planes(P, ray, h);
 
     f3 inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     int neg = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
@@ -624,8 +637,7 @@ PTK_DEV bool trav_is_leaf(const Trav& T) { return T.cur != ENTRY_NONE && (int)T.
 PTK_DEV bool trav_is_inner(const Trav& T) { return T.cur != ENTRY_NONE && (int)T.cur > 0; }
 
 // Entry into a mesh socket at world level (:1286-1313): the ray is taken into the mesh's space.
-PTK_DEV void trav_enter_mesh(const PtkParams& P, Trav& T, int xf) {
-    const m44 M = load_xform(P, xf);
+PTK_DEV void trav_enter_mesh_m(Trav& T, const m44& M, int xf) {
     T.w_o = T.o; T.w_d = T.d; T.w_start = T.start;
     const f3 unnorm = mul_mv(M, T.d, 0.0f);
     T.dir_len = length3(unnorm);
@@ -638,6 +650,7 @@ PTK_DEV void trav_enter_mesh(const PtkParams& P, Trav& T, int xf) {
     T.sub_base = T.sp;
     T.cur_xf = xf;
 }
+PTK_DEV void trav_enter_mesh(const PtkParams& P, Trav& T, int xf) { trav_enter_mesh_m(T, load_xform(P, xf), xf); }
 
 // hit_AABB (:670-689) and the acceptance test of :1152 for the only child of a one-child node: the same
 // operations, in the same order, as one slot of the packed test in trav_inner.
@@ -668,7 +681,7 @@ PTK_DEV void trav_begin(const PtkParams& P, Trav& T, const Ray& world_ray) {
     const PtkWavefront& W = P.wf;
     Ray r = world_ray;
     T.h.hit = 0; T.h.object_id = 0; T.h.transform_index = -1; T.h.u = 0.0f; T.h.v = 0.0f;
-    for (int i = 0; i < P.n_live_planes; ++i) hit_plane(P, r, T.h, P.live_planes[i], -1);
+    hit_live_planes(P, r, T.h);
     T.o = r.o; T.d = r.d; T.start = r.start; T.end = r.end;
     T.inv = mk3(1.0f / T.d.x, 1.0f / T.d.y, 1.0f / T.d.z);
     const int neg = (T.inv.x < 0.0f ? 1 : 0) | (T.inv.y < 0.0f ? 2 : 0) | (T.inv.z < 0.0f ? 4 : 0);
@@ -682,7 +695,14 @@ PTK_DEV void trav_begin(const PtkParams& P, Trav& T, const Ray& world_ray) {
     T.dir_len = 1.0f;
     for (int s = 0; s < W.n_chain; s++) {  // (uniform over the wave: the steps are kernel arguments)
         const PtkChainStep& c = W.chain[s];
-        if (c.kind == 1) { if (alive) trav_enter_mesh(P, T, c.xf); }
+        if (c.kind == 1) {
+            if (alive) {
+                m44 M;
+                M.c0 = make_float4(c.m[0], c.m[1], c.m[2], c.m[3]); M.c1 = make_float4(c.m[4], c.m[5], c.m[6], c.m[7]);
+                M.c2 = make_float4(c.m[8], c.m[9], c.m[10], c.m[11]); M.c3 = make_float4(c.m[12], c.m[13], c.m[14], c.m[15]);
+                trav_enter_mesh_m(T, M, c.xf);
+            }
+        }
         else if (alive) alive = trav_single_child_accepts(T, c);
     }
     T.cur = alive ? W.root_entry : ENTRY_NONE;

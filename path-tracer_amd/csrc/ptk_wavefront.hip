@@ -204,7 +204,10 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
     }
     // words the waves of the workgroup tell each other through: [0] one of them found the queue dry,
     // [1] how many have parked their searches or left, [2..3] the workgroup's chunk of the queue
-    volatile int* const wg_flags = lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64;
+    // (an LDS-address-space pointer: through a generic pointer these reads, made in every round, would be flat loads
+    // that take the vector-memory path and wait for every load in flight)
+    typedef volatile int __attribute__((address_space(3))) * LdsFlags;
+    const LdsFlags wg_flags = (LdsFlags)(lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64);
     unsigned long long* const wg_range = (unsigned long long*)(lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64 + 2);  // see wg_claim
     Stack S;
     S.top = (PtkLdsBlocks)lds_all; S.n_top = W.n_top;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
                 // the queue is dry: park what is still searching, unless the path is too far behind already or
                 // part of its stack lives in the spill column
                 parked = true;
-                if (lane == 0) atomicAdd((int*)wg_flags + 1, 1);
+                if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)wg_flags + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const bool park = have && T.cur != ENTRY_NONE && T.sp <= S.lds_cap && iter - ray_bounce < W.max_lag;
                 const unsigned long long pm = __ballot(park);
                 if (pm != 0ull) {
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
             }
             PTK_ST_ROUND_END(2);
             if (exhausted && __ballot(have) == 0ull) {
-                if (!parked && lane == 0) atomicAdd((int*)wg_flags + 1, 1);
+                if (!parked && lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)wg_flags + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 break;
             }
         }
