@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 tag=$1
 run() {  # name, counters
-  timeout -s KILL 240 rocprofv3 --pmc $2 -d $R/gpurun_out/pmc_${tag}_$1 --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_${tag}_$1.log 2>&1
+  timeout -s KILL 240 rocprofv3 --pmc $2 -d $R/gpurun_out/pmc_${tag}_$1 --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-configs > $R/gpurun_out/pmc_${tag}_$1.log 2>&1
 }
 run A "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAVES"
 run B "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum"
