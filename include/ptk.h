@@ -141,8 +141,8 @@ int ptk_texture_bind(ptk_ctx* ctx, uint64_t texture, int slot);
  * of _push_constant_byte_array (:771-808); groups are 8x8x1 invocations
  * (ray_tracer.comp:55).  Asynchronous on the context's stream. */
 int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, int groups_z);
-/* ptk_dispatch for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same image
+/* ptk_dispatch for callers that cannot allocate device memory (serving loops with a fixed memory budget, harnesses
+ * that forbid hipMalloc while rendering).  No counterpart in the reference.  Same arguments, same image
  * bit for bit as ptk_dispatch; rendered by the persistent path kernel, whose pixel counter and
  * traversal-stack spill column live in a static 8 MiB device array of the library (one copy per GPU, held
  * until the process ends) instead of allocated buffers.  It calls no hipMalloc / hipFree.  Conditions,
@@ -151,11 +151,13 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
  *     allocates the derived tables): PTK_E_STATE otherwise;
  *   - plain render mode with the BVH flag, no tracing, no early-t variant, max_default_depth > 0, no mesh
  *     socket below another: PTK_E_UNSUPPORTED otherwise;
- *   - the bound BVH's deepest traversal stack must fit: 32 entries per ray are kept on chip, the rest in the
+ *   - the bound BVH's deepest traversal stack must fit: 20 entries per ray are kept on chip, the rest in the
  *     static array, which at one wave per compute unit holds (8 MiB - 256) / (CUs * 256 B) further entries
  *     (127 on a 256-CU MI355X); a deeper tree is PTK_E_UNSUPPORTED.
- * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two contexts, two
- * streams) race on it; calls on one context are ordered on its stream and do not. */
+ * All calls on one GPU share that GPU's array.  The library orders them: a call waits, on its context's stream, for
+ * the end of the last launch on that GPU that used the array (an event recorded behind every such launch), so two
+ * contexts may both use this entry point; their dispatches then run one after the other.  The launch is issued on
+ * the context's own stream, not on one the caller could be capturing into a HIP graph. */
 int ptk_dispatch_noalloc(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, int groups_z);
 /* Replaces rd.submit() + rd.sync(), pt_work_dispatcher.gd:494-497. */
 int ptk_sync(ptk_ctx* ctx);

@@ -140,7 +140,9 @@ struct ptk_ctx {
     size_t display_bytes = 0;
     size_t wf_spill_ints = 0;
     int n_cus = 0;
-    int lds_window = 32;           // traversal stack entries per lane kept in LDS (PTK_LDS_WINDOW, read once at create)
+    int lds_window = 20;           // traversal stack entries per lane kept in LDS, deeper ones spill to a global column
+                                   // (PTK_LDS_WINDOW, read once at create; what the stacks leave of a compute unit's LDS holds
+                                   // the top node blocks: 12 / 16 / 20 / 24 / 32 rows gave 8.53 / 7.76 / 7.62 / 7.63 / 7.69 ms per step)
     bool wf_carry = true;          // the pipeline parks unfinished searches for the next launch (PTK_WF_CARRY=0 turns it off; read once at create)
     int wf_max_lag = 2, wf_park_below = 16;  // (PTK_WF_MAX_LAG, PTK_WF_PARK_BELOW: tuning, read once at create)
     int leaf_redo_all = 0;         // (PTK_LEAF_REDO_ALL=1: exercises trav_leaf's fallback on every helped leaf; for tests)
@@ -229,7 +231,9 @@ ptk_ctx* ptk_create(int device_ordinal) {
     ok = ok && hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess;
     if (ok) ctx->n_cus = prop.multiProcessorCount;
     // development knobs are read here once: a variable that appears in the host's environment later changes nothing
-    if (const char* w = getenv("PTK_LDS_WINDOW")) ctx->lds_window = std::max(8, std::min(64, atoi(w)));
+    // (at most as many rows as sixteen waves' windows, their spare rows and the workgroup's words fit a compute unit's LDS)
+    const int max_window = (int)((PTK_LDS_BYTES_PER_CU - PTK_WF_WG_FLAG_BYTES) / (PTK_WF_WG_WAVES * 256)) - 1;
+    if (const char* w = getenv("PTK_LDS_WINDOW")) ctx->lds_window = std::max(8, std::min(max_window, atoi(w)));
     if (const char* w = getenv("PTK_WF_CARRY")) ctx->wf_carry = atoi(w) != 0;
     if (const char* w = getenv("PTK_WF_MAX_LAG")) ctx->wf_max_lag = std::max(1, std::min(PTK_WF_MAX_LAG, atoi(w)));
     if (const char* w = getenv("PTK_WF_PARK_BELOW")) ctx->wf_park_below = std::max(1, std::min(64, atoi(w)));
@@ -1079,12 +1083,19 @@ static int validate_scene(ptk_ctx* ctx) {
     ctx->slot_is_dirty.assign((size_t)std::max(n_ids, 1), 0);
     { int r = refresh_live_planes(ctx, pln); if (r != PTK_OK) return r; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    // persistent waves per CU of both persistent kernels at this scene's LDS need (window + one spare row)
+    // persistent waves per CU of both persistent kernels at this scene's LDS need (window + one spare row); a kernel
+    // that does not fit (or whose occupancy cannot be asked) is not eligible for this scene, the others still are
     {
         const size_t lds = (size_t)(std::min(ctx->stack_need, ctx->lds_window) + 1) * 64 * 4;
-        HIP_TRY(ctx, ptk_wavefront_occupancy((size_t)ctx->n_top * PTK_TOP_BLOCK_STRIDE + PTK_WF_WG_WAVES * lds + PTK_WF_WG_FLAG_BYTES, &ctx->wf_wgs_per_cu));
-        HIP_TRY(ctx, ptk_persistent_occupancy(lds, ctx->n_top, &ctx->pp_wg_waves, &ctx->pp_wgs_per_cu));
-        if (ctx->waves_per_cu_cap > 0 && ctx->pp_wg_waves > 0)
+        if (ptk_wavefront_occupancy((size_t)ctx->n_top * PTK_TOP_BLOCK_STRIDE + PTK_WF_WG_WAVES * lds + PTK_WF_WG_FLAG_BYTES, &ctx->wf_wgs_per_cu) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->wf_wgs_per_cu = 0;
+        }
+        if (ptk_persistent_occupancy(lds, ctx->n_top, &ctx->pp_wg_waves, &ctx->pp_wgs_per_cu) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->pp_wgs_per_cu = 0;
+        }
+        if (ctx->waves_per_cu_cap > 0 && ctx->pp_wg_waves > 0 && ctx->pp_wgs_per_cu > 0)
             ctx->pp_wgs_per_cu = std::max(1, std::min(ctx->pp_wgs_per_cu, ctx->waves_per_cu_cap / ctx->pp_wg_waves));
     }
     ctx->dirty = false;
@@ -1222,7 +1233,7 @@ static void fill_blocks(const ptk_ctx* ctx, PtkParams& P) {
 // dispatch: plain render mode over the BVH, untraced, no early-t variant, at least one bounce.
 static bool persistent_covers(const ptk_ctx* ctx, const PtkPush& push, bool trace) {
     const int fl = push.flags;
-    return ctx->wf_ok && fl >= 0 && (fl & 1) && push.render_mode != 1 && push.render_mode != 2 && !trace &&
+    return ctx->wf_ok && ctx->pp_wgs_per_cu > 0 && fl >= 0 && (fl & 1) && push.render_mode != 1 && push.render_mode != 2 && !trace &&
            !ctx->early_t_break && push.max_default_depth > 0;
 }
 
@@ -1301,7 +1312,7 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     const int rb_max = std::max(P.push.max_refraction_bounces - 1, 0);
     const int n_iter = P.push.max_default_depth + rb_max;  // most bounces any path can take (ray_tracer.comp:1572)
     const bool pp_eligible = persistent_covers(ctx, P.push, trace != 0);
-    const bool wf_eligible = pp_eligible && n_iter <= PTK_WF_MAX_ITER;  // the pipeline launches once per bounce
+    const bool wf_eligible = pp_eligible && ctx->wf_wgs_per_cu > 0 && n_iter <= PTK_WF_MAX_ITER;  // the pipeline launches once per bounce
     int choice = 0;  // 0 one-kernel renderer, 1 wavefront pipeline, 2 persistent path kernel
     if (ctx->renderer == PTK_RENDERER_WAVEFRONT) {
         if (!wf_eligible)
@@ -1527,7 +1538,7 @@ int ptk_dispatch_noalloc(ptk_ctx* ctx, const void* push128, int groups_x, int gr
     ctx->wf_iters[slot] = 0;
     ctx->last_choice = 2;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
-    HIP_TRY(ctx, ptk_launch_persistent(&P, pp_lds, (int)n_wgs, ctx->pp_wg_waves, ctx->stream));
+    HIP_TRY(ctx, ptk_launch_persistent_static(&P, pp_lds, (int)n_wgs, ctx->pp_wg_waves, ctx->device, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
     ctx->dispatch_count++;
     return PTK_OK;

@@ -164,6 +164,9 @@ extern "C" hipError_t ptk_persistent_occupancy(size_t lds_per_wave, uint32_t n_t
 #define PTK_NOALLOC_SCRATCH_BYTES ((size_t)8 << 20)
 extern "C" hipError_t ptk_persistent_scratch_init(int device);
 extern "C" void* ptk_persistent_scratch(int device);
+// ptk_launch_persistent for a dispatch whose scratch is that array: waits (on `stream`) for the last launch on this GPU
+// that used the array, launches, records its own end for the next one.  Allocates nothing.
+extern "C" hipError_t ptk_launch_persistent_static(const PtkParams* p, size_t lds_per_wave, int n_wgs, int wg_waves, int device, hipStream_t stream);
 // Display conversion (ptk_display.hip): rgba32f image -> RGBA8, n_pixels * 4 bytes at out_rgba8 (device, 16-byte aligned).
 extern "C" hipError_t ptk_launch_display(const float4* image, void* out_rgba8, size_t n_pixels, int transfer, hipStream_t stream);
 extern "C" hipError_t ptk_launch_scale(float4* image, size_t n_pixels, float s, hipStream_t stream);

@@ -203,6 +203,10 @@ static __device__ __align__(256) unsigned char scratch[PTK_NOALLOC_SCRATCH_BYTES
 namespace {
 constexpr int kMaxDevices = 64;
 void* g_scratch_ptr[kMaxDevices] = {nullptr};  // device address of `scratch` on each GPU (the array's name is not one)
+// Every context on a GPU shares that GPU's array, each on a stream of its own: the end of the last launch that used
+// the array is recorded here, and the next one waits for it on its stream before it touches the array.
+hipEvent_t g_scratch_event[kMaxDevices] = {nullptr};
+bool g_scratch_in_use[kMaxDevices] = {false};
 std::mutex g_scratch_mutex;
 }  // namespace
 
@@ -215,6 +219,8 @@ extern "C" hipError_t ptk_persistent_scratch_init(int device) {
     hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
     if (e != hipSuccess) return e;
     if (!ptr) return hipErrorInvalidSymbol;
+    e = hipEventCreateWithFlags(&g_scratch_event[device], hipEventDisableTiming);  // (made here, so that the entry point itself creates nothing)
+    if (e != hipSuccess) return e;
     g_scratch_ptr[device] = ptr;
     return hipSuccess;
 }
@@ -251,4 +257,21 @@ extern "C" hipError_t ptk_launch_persistent(const PtkParams* p, size_t lds_per_w
     const size_t lds = (size_t)p->wf.n_top * PTK_TOP_BLOCK_STRIDE + (size_t)wg_waves * lds_per_wave + PTK_WF_WG_FLAG_BYTES;
     hipLaunchKernelGGL(ptk_path_kernel, dim3((unsigned)n_wgs), dim3((unsigned)wg_waves * 64), lds, stream, *p);
     return hipGetLastError();
+}
+
+// ptk_launch_persistent with the pixel counter and the spill column in the static array (p->wf.heads / p->spill point
+// into it): ordered behind the last launch on this GPU that used the array, whichever context and stream issued it.
+// The lock is held from the wait to the record, so that two host threads cannot both wait on the older event.
+extern "C" hipError_t ptk_launch_persistent_static(const PtkParams* p, size_t lds_per_wave, int n_wgs, int wg_waves, int device, hipStream_t stream) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_event[device]) return hipErrorNotInitialized;
+    hipError_t e = hipSuccess;
+    if (g_scratch_in_use[device]) e = hipStreamWaitEvent(stream, g_scratch_event[device], 0);
+    if (e != hipSuccess) return e;
+    e = ptk_launch_persistent(p, lds_per_wave, n_wgs, wg_waves, stream);
+    if (e != hipSuccess) return e;
+    e = hipEventRecord(g_scratch_event[device], stream);
+    g_scratch_in_use[device] = e == hipSuccess;
+    return e;
 }

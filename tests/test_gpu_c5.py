@@ -123,9 +123,13 @@ def deep_chain_scene(pta, depth=6, seed=3):
     return scene, packed
 
 
-def test_stack_deeper_than_the_lds_window(pta):
-    """Stack need 43 > 32: entries past the LDS window go to the global spill column in all three
-    schedules and in the traced tile kernel; everything equals the oracle."""
+@pytest.mark.parametrize("window", [None, "64", "8"])
+def test_stack_deeper_than_the_lds_window(pta, monkeypatch, window):
+    """Stack need 43 > the LDS window (20 by default; the largest a compute unit holds when 64 is asked for; 8):
+    entries past the window go to the global spill column in all three schedules and in the traced tile kernel;
+    everything equals the oracle."""
+    if window is not None:
+        monkeypatch.setenv("PTK_LDS_WINDOW", window)
     wd = pta.work_dispatcher
     scene, packed = deep_chain_scene(pta, depth=6)
     w, h = 160, 96

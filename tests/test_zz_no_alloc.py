@@ -48,7 +48,7 @@ def _push(wd, scene, w, h, k, gx=None, gy=None, depth=6):
 def test_noalloc_equals_dispatch_twice_second_smaller(pta, golden_dir, case):
     wd = pta.work_dispatcher
     if case == "deep_chain":
-        scene, packed = deep_chain_scene(pta, depth=6)  # stack need 43: 11 entries per lane spill into the static array
+        scene, packed = deep_chain_scene(pta, depth=6)  # stack need 43: 23 entries per lane spill into the static array
     else:
         scene = pta.scenes.load_fixture_scene("benchmark_random_scene", golden_dir)
         packed = wd.pack_scene(scene, ob.OracleBvhBuilder(), 8)
@@ -95,6 +95,42 @@ def test_noalloc_equals_dispatch_twice_second_smaller(pta, golden_dir, case):
             dev.close()
 
 
+def test_two_contexts_share_the_static_array(pta, golden_dir):
+    """Two contexts on one GPU, each on its own stream, both through ptk_dispatch_noalloc back to back without a sync
+    in between, several rounds: the library orders their launches on the shared array, so each image equals what
+    ptk_dispatch gives (and the oracle)."""
+    wd = pta.work_dispatcher
+    scene, packed = deep_chain_scene(pta, depth=6)  # uses the spill part of the array as well as the counter
+    w, h = 320, 184
+    (a, da), (b, db) = _pair(pta, packed, w, h)
+    try:
+        win, push = _push(wd, scene, w, h, 0)
+        for dev, d in ((a, da), (b, db)):
+            dev.compute_list_dispatch(push, win.work_group_width, win.work_group_height, 1)
+            dev.sync()
+            dev.texture_update(d.image_buffer, np.zeros((h, w, 4), np.float32))
+        free_before = _hip_free_bytes()
+        rounds = 6
+        for k in range(rounds):
+            win, push = _push(wd, scene, w, h, k)
+            a.compute_list_dispatch_noalloc(push, win.work_group_width, win.work_group_height, 1)
+            b.compute_list_dispatch_noalloc(push, win.work_group_width, win.work_group_height, 1)
+        a.sync()
+        b.sync()
+        assert _hip_free_bytes() == free_before, "device memory was allocated or freed"
+        cpu = np.zeros((h, w, 4), np.float32)
+        for k in range(rounds):
+            win, push = _push(wd, scene, w, h, k)
+            ob.render(packed, push, cpu, win.work_group_width, win.work_group_height, trace=False)
+        for name, (dev, d) in (("first", (a, da)), ("second", (b, db))):
+            img = dev.texture_get_data(d.image_buffer)
+            assert np.array_equal(img.view(np.uint32), cpu.view(np.uint32)), f"{name} context: {np.count_nonzero(img != cpu)} words differ from the oracle"
+    finally:
+        for dev, d in ((a, da), (b, db)):
+            d.free_rids()
+            dev.close()
+
+
 def test_noalloc_error_paths(pta, golden_dir):
     wd = pta.work_dispatcher
     scene = pta.scenes.load_fixture_scene("sphere_scene1", golden_dir)
@@ -123,7 +159,7 @@ def test_noalloc_error_paths(pta, golden_dir):
     finally:
         dev.close()
     # a tree whose stack need is beyond what the static array holds at one wave per CU: refused with the limit named
-    scene, packed = deep_chain_scene(pta, depth=30)  # need 7 * 29 + 8 = 211 > 32 + 127
+    scene, packed = deep_chain_scene(pta, depth=30)  # need 7 * 29 + 8 = 211 > 20 + 127
     dev = pta.PtkRenderingDevice(0)
     try:
         d = wd.PTWorkDispatcher(dev)

@@ -2,7 +2,7 @@
 var=$1; shift
 for v in "$@"; do
 export $var=$v
-timeout -k 10 200 python -u bench.py --no-cpu-baseline > gpurun_out/ab.json 2>/dev/null || exit 1
+timeout -k 10 200 python -u bench.py --no-cpu-baseline --no-configs > gpurun_out/ab.json 2>/dev/null || exit 1
 b=$(python3 -c "
 import json; b=json.load(open('gpurun_out/ab.json')); print(round(b['ms_per_step'],3))")
 l=""
