@@ -1555,6 +1555,16 @@ int ptk_dev_wf_stats(ptk_ctx* ctx, unsigned long long* out, int n) {
 }
 #endif
 
+#ifdef PTK_WF_STATS
+extern "C" hipError_t ptk_pp_stats_fetch(unsigned long long* out, hipStream_t stream);
+int ptk_dev_pp_stats(ptk_ctx* ctx, unsigned long long* out8) {
+    if (!ctx || !out8) return PTK_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, ptk_pp_stats_fetch(out8, ctx->stream));
+    return PTK_OK;
+}
+#endif
+
 #ifdef PTK_WF_ENDS
 extern "C" hipError_t ptk_wf_ends_fetch(unsigned long long* out, size_t n, hipStream_t stream);
 int ptk_dev_wf_ends(ptk_ctx* ctx, unsigned long long* out, size_t n) {

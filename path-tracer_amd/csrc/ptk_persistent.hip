@@ -42,6 +42,21 @@ enum : int { PP_IDLE = 0, PP_SEARCH = 1, PP_HIT = 2 };
 
 }  // namespace
 
+#ifdef PTK_WF_STATS
+// Measurement build: shader-clock ticks the waves spent in inner / leaf / refill / bounce rounds [0..3] and the
+// numbers of those rounds [4..7].
+__device__ unsigned long long g_pp_stats[8];
+extern "C" hipError_t ptk_pp_stats_fetch(unsigned long long* out, hipStream_t stream) {
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    unsigned long long h[8];
+    e = hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pp_stats), sizeof h);
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < 8; i++) { out[i] = h[i]; h[i] = 0; }
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pp_stats), h, sizeof h);
+}
+#endif
+
 __global__ __launch_bounds__(PTK_PP_MAX_WG_WAVES * 64) void ptk_path_kernel(const PtkParams P) {
     // [top blocks: n_top * 272 bytes][per wave: stack window [entry][lane], P.lds_cap rows + one spare row][16 bytes: claim word]
     extern __shared__ __attribute__((aligned(16))) int lds_all[];
@@ -85,111 +100,144 @@ __global__ __launch_bounds__(PTK_PP_MAX_WG_WAVES * 64) void ptk_path_kernel(cons
     T.cur = ENTRY_NONE; T.sp = 0; T.sub_base = 0; T.cur_xf = -1;
     T.w_o = mk3(0, 0, 0); T.w_d = mk3(0, 0, 1); T.w_start = 0.0f; T.dir_len = 1.0f;
 
+#ifdef PTK_WF_STATS
+    long long st_clk[4] = {0, 0, 0, 0};  // shader-clock ticks this wave spent in inner / leaf / refill / bounce rounds
+    long long st_n[4] = {0, 0, 0, 0};
+#define PTK_PP_ROUND_BEGIN() const long long st_c0 = clock64()
+#define PTK_PP_ROUND_END(k) (st_clk[k] += clock64() - st_c0, st_n[k]++)
+#else
+#define PTK_PP_ROUND_BEGIN()
+#define PTK_PP_ROUND_END(k)
+#endif
+    // Two nested loops: bounce and refill rounds in the outer one, search rounds in the inner one until a round of
+    // another kind is due.  (As branches of one loop, the rounds that replace a lane's whole path state made the
+    // compiler carry a second copy of it through every search round.)
     for (;;) {
-        const bool searching = phase == PP_SEARCH;
-        const bool is_leaf = searching && trav_is_leaf(T);
-        const bool is_inner = searching && trav_is_inner(T);
-        const unsigned long long mi = __ballot(is_inner), ml = __ballot(is_leaf);
-        const bool none_searching = (mi | ml) == 0ull;
-        const int n_hit = __popcll(__ballot(phase == PP_HIT));
-        const int n_idle = __popcll(__ballot(phase == PP_IDLE));
+        {
+            PTK_PP_ROUND_BEGIN();
+            const unsigned long long m_search = __ballot(phase == PP_SEARCH);
+            const bool none_searching = m_search == 0ull;
+            const int n_hit = __popcll(__ballot(phase == PP_HIT));
+            const int n_idle = __popcll(__ballot(phase == PP_IDLE));
 
-        if (n_hit > 0 && (none_searching || PTK_PP_BOUNCE_NOW(n_hit, __popcll(mi | ml)))) {
-            // ---- bounce round: the loop body of cast_ray after the search (:1583-1621) ----
-            if (phase == PP_HIT) {
-                // the search ends at world level, so T.o / T.d are the segment's ray and T.end its hit distance
-                Ray nr;
-                nr.o = T.o; nr.d = T.d; nr.start = 0.0f; nr.end = T.end;
-                const Hit h = T.h;
-                bool done;
-                if (!h.hit) {
-                    const float4 sky = P.use_emission ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(0.7f, 0.7f, 0.9f, 1.0f);
-                    color = make_float4(color.x * sky.x, color.y * sky.y, color.z * sky.z, color.w * sky.w);
-                    done = true;
-                } else {
-                    Surf s = determine_rayhit<false>(P, L, nr, h, nullptr);
-                    if (P.use_emission && L.is_emissive) {
-                        color = make_float4(color.x * s.albedo.x, color.y * s.albedo.y, color.z * s.albedo.z, color.w * 1.0f);
+            if (n_hit > 0 && (none_searching || PTK_PP_BOUNCE_NOW(n_hit, __popcll(m_search)))) {
+                // ---- bounce round: the loop body of cast_ray after the search (:1583-1621) ----
+                if (phase == PP_HIT) {
+                    // the search ends at world level, so T.o / T.d are the segment's ray and T.end its hit distance
+                    Ray nr;
+                    nr.o = T.o; nr.d = T.d; nr.start = 0.0f; nr.end = T.end;
+                    const Hit h = T.h;
+                    bool done;
+                    if (!h.hit) {
+                        const float4 sky = P.use_emission ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(0.7f, 0.7f, 0.9f, 1.0f);
+                        color = make_float4(color.x * sky.x, color.y * sky.y, color.z * sky.z, color.w * sky.w);
                         done = true;
                     } else {
-                        const float4 tex_col = get_texture(P, s);
-                        nr = bounce_ray(P, L, nr, s);
-                        if (!L.ignore_attenuation) {
-                            color.x *= s.albedo.x * tex_col.x;
-                            color.y *= s.albedo.y * tex_col.y;
-                            color.z *= s.albedo.z * tex_col.z;
-                            color.w *= 1.0f * tex_col.w;
+                        Surf s = determine_rayhit<false>(P, L, nr, h, nullptr);
+                        if (P.use_emission && L.is_emissive) {
+                            color = make_float4(color.x * s.albedo.x, color.y * s.albedo.y, color.z * s.albedo.z, color.w * 1.0f);
+                            done = true;
                         } else {
-                            L.ignore_attenuation = 0;
+                            const float4 tex_col = get_texture(P, s);
+                            nr = bounce_ray(P, L, nr, s);
+                            if (!L.ignore_attenuation) {
+                                color.x *= s.albedo.x * tex_col.x;
+                                color.y *= s.albedo.y * tex_col.y;
+                                color.z *= s.albedo.z * tex_col.z;
+                                color.w *= 1.0f * tex_col.w;
+                            } else {
+                                L.ignore_attenuation = 0;
+                            }
+                            bounce++;
+                            done = !(bounce < P.push.max_default_depth + L.refraction_bounces);
                         }
-                        bounce++;
-                        done = !(bounce < P.push.max_default_depth + L.refraction_bounces);
+                    }
+                    if (done) {  // the end of main() (:1683-1704)
+                        if (P.use_emission && !L.is_emissive) color = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        const uint32_t tile = slot >> 6, l = slot & 63u;
+                        const int gx = (int)(tile % (uint32_t)W.tiles_x) * 8 + (int)(l & 7u);
+                        const int gy = (int)(tile / (uint32_t)W.tiles_x) * 8 + (int)(l >> 3);
+                        store_pixel(P, gx + P.push.image_offset_x, gy + P.push.image_offset_y, color, false, color);
+                        phase = PP_IDLE;
+                    } else {
+                        trav_begin(P, T, nr);
+                        phase = T.cur == ENTRY_NONE ? PP_HIT : PP_SEARCH;  // (a ray that misses the root box has its result already)
                     }
                 }
-                if (done) {  // the end of main() (:1683-1704)
-                    if (P.use_emission && !L.is_emissive) color = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    const uint32_t tile = slot >> 6, l = slot & 63u;
-                    const int gx = (int)(tile % (uint32_t)W.tiles_x) * 8 + (int)(l & 7u);
-                    const int gy = (int)(tile / (uint32_t)W.tiles_x) * 8 + (int)(l >> 3);
-                    store_pixel(P, gx + P.push.image_offset_x, gy + P.push.image_offset_y, color, false, color);
-                    phase = PP_IDLE;
-                } else {
-                    trav_begin(P, T, nr);
-                    phase = T.cur == ENTRY_NONE ? PP_HIT : PP_SEARCH;  // (a ray that misses the root box has its result already)
-                }
+                PTK_PP_ROUND_END(3);
+                continue;
             }
-            continue;
-        }
 
-        if (!exhausted && n_idle > 0 && (none_searching || n_idle >= PTK_PP_REFILL)) {
-            // ---- refill round: idle lanes take the next pixels and start their paths (:1645-1681) ----
+            if (!exhausted && n_idle > 0 && (none_searching || n_idle >= PTK_PP_REFILL)) {
+                // ---- refill round: idle lanes take the next pixels and start their paths (:1645-1681) ----
 #pragma unroll 1
-            for (int pass = 0; pass < 2 && !exhausted; pass++) {
-                const unsigned long long need = __ballot(phase == PP_IDLE);
-                if (need == 0ull) break;
-                if (c_next == c_end) {
-                    const int got = wg_claim(wg_range, W.heads, wg_chunk, n_slots, lane, c_next, c_end);
-                    if (got == CLAIM_DRY) { exhausted = true; break; }
-                    if (got == CLAIM_LATER) { __builtin_amdgcn_s_sleep(1); break; }  // another wave is fetching the workgroup's next chunk
-                }
-                const uint32_t avail = c_end - c_next;
-                const uint32_t my = (uint32_t)pp_rank_in(need);
-                if (phase == PP_IDLE && my < avail) {
-                    slot = c_next + my;
-                    const uint32_t tile = slot >> 6, l = slot & 63u;
-                    const int gx = (int)(tile % (uint32_t)W.tiles_x) * 8 + (int)(l & 7u);
-                    const int gy = (int)(tile / (uint32_t)W.tiles_x) * 8 + (int)(l >> 3);
-                    const Primary pr = primary_ray(P.push, gx, gy);
-                    L.current_IOR = 1.0f; L.inside_of_count = 0; L.seed = pr.seed;
+                for (int pass = 0; pass < 2 && !exhausted; pass++) {
+                    const unsigned long long need = __ballot(phase == PP_IDLE);
+                    if (need == 0ull) break;
+                    if (c_next == c_end) {
+                        const int got = wg_claim(wg_range, W.heads, wg_chunk, n_slots, lane, c_next, c_end);
+                        if (got == CLAIM_DRY) { exhausted = true; break; }
+                        if (got == CLAIM_LATER) { __builtin_amdgcn_s_sleep(1); break; }  // another wave is fetching the workgroup's next chunk
+                    }
+                    const uint32_t avail = c_end - c_next;
+                    const uint32_t my = (uint32_t)pp_rank_in(need);
+                    if (phase == PP_IDLE && my < avail) {
+                        slot = c_next + my;
+                        const uint32_t tile = slot >> 6, l = slot & 63u;
+                        const int gx = (int)(tile % (uint32_t)W.tiles_x) * 8 + (int)(l & 7u);
+                        const int gy = (int)(tile / (uint32_t)W.tiles_x) * 8 + (int)(l >> 3);
+                        const Primary pr = primary_ray(P.push, gx, gy);
+                        L.current_IOR = 1.0f; L.inside_of_count = 0; L.seed = pr.seed;
 #pragma unroll
-                    for (int i = 0; i < MAX_OVERLAP; i++) { L.in_mat[i] = 0; L.in_pri[i] = INT_NEG_LIMIT; }
-                    L.is_emissive = 0; L.refraction_bounces = 0; L.ignore_attenuation = 0;
-                    color = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-                    bounce = 0;
-                    trav_begin(P, T, pr.ray);
-                    phase = T.cur == ENTRY_NONE ? PP_HIT : PP_SEARCH;
+                        for (int i = 0; i < MAX_OVERLAP; i++) { L.in_mat[i] = 0; L.in_pri[i] = INT_NEG_LIMIT; }
+                        L.is_emissive = 0; L.refraction_bounces = 0; L.ignore_attenuation = 0;
+                        color = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                        bounce = 0;
+                        trav_begin(P, T, pr.ray);
+                        phase = T.cur == ENTRY_NONE ? PP_HIT : PP_SEARCH;
+                    }
+                    const uint32_t wanted = (uint32_t)__popcll(need);
+                    c_next += wanted < avail ? wanted : avail;
                 }
-                const uint32_t wanted = (uint32_t)__popcll(need);
-                c_next += wanted < avail ? wanted : avail;
+                PTK_PP_ROUND_END(2);
+                continue;
             }
-            continue;
+
+            if (none_searching) break;  // nothing to search, no bounce due, no pixel left to claim
         }
 
-        if (none_searching) break;  // nothing to search, no bounce due, no pixel left to claim
-
-        // ---- search round: the larger group of searching lanes advances, the other waits ----
-        bool pop = false;
-        if (PTK_VOTE_INNER(__popcll(mi), __popcll(ml))) {
-            if (is_inner) pop = trav_inner(P, S, T);
-        } else {
-            trav_leaf(P, S, T, is_leaf);
-            pop = is_leaf;
-        }
-        if (pop) {
-            trav_pop(S, T);
-            if (T.cur == ENTRY_NONE) phase = PP_HIT;
+        // ---- search rounds: the larger group of searching lanes advances, the other waits ----
+        for (;;) {
+            PTK_PP_ROUND_BEGIN();
+            const bool searching = phase == PP_SEARCH;
+            const bool is_leaf = searching && trav_is_leaf(T);
+            const bool is_inner = searching && trav_is_inner(T);
+            const unsigned long long mi = __ballot(is_inner), ml = __ballot(is_leaf);
+            const bool inner_round = PTK_VOTE_INNER(__popcll(mi), __popcll(ml));
+            bool pop = false;
+            if (inner_round) {
+                if (is_inner) pop = trav_inner(P, S, T);
+            } else {
+                trav_leaf(P, S, T, is_leaf);
+                pop = is_leaf;
+            }
+            if (pop) {
+                trav_pop(S, T);
+                if (T.cur == ENTRY_NONE) phase = PP_HIT;
+            }
+            PTK_PP_ROUND_END(inner_round ? 0 : 1);
+            // is a round of another kind due (the tests of the outer loop)?
+            const unsigned long long m_search = __ballot(phase == PP_SEARCH);
+            const int n_hit = __popcll(__ballot(phase == PP_HIT));
+            const int n_idle = 64 - n_hit - __popcll(m_search);
+            if (m_search == 0ull) break;
+            if (n_hit > 0 && PTK_PP_BOUNCE_NOW(n_hit, __popcll(m_search))) break;
+            if (!exhausted && n_idle >= PTK_PP_REFILL) break;
         }
     }
+#ifdef PTK_WF_STATS
+    if (lane == 0) for (int k = 0; k < 4; k++) { atomicAdd(&g_pp_stats[k], (unsigned long long)st_clk[k]); atomicAdd(&g_pp_stats[4 + k], (unsigned long long)st_n[k]); }
+#endif
 }
 
 // ---- static scratch for ptk_dispatch_noalloc --------------------------------------------------------
