@@ -45,7 +45,9 @@ struct PtkTexDesc {
 // entry i is hits[i] = {hit, object_id, transform_index, bits(t)} and hit_uv[i].
 #define PTK_WF_MAX_ITER 64
 #define PTK_WF_MAX_LAG 8       // launches a path may fall behind its bounce number by being carried over (see PtkWavefront::carry)
+#ifndef PTK_PP_MAX_WG_WAVES
 #define PTK_PP_MAX_WG_WAVES 12  // waves of a path-kernel workgroup (three per SIMD at its register count)
+#endif
 #define PTK_WF_WG_FLAG_BYTES 16 // LDS words the waves of a workgroup share besides the top blocks: queue dry, waves done, the claim word (wg_claim)
 #define PTK_WF_CARRY_PLANES 25 // words of search state carried besides the stack rows
 // The top of many trees is a chain every ray walks in the same way: a root with one child, a mesh socket, a

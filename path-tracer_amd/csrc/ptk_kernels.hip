@@ -18,9 +18,17 @@
 
 #include "ptk_render_core.h"
 
+// Four waves per SIMD for the untraced block-traversal variant (the one plain rendering runs): it needs some 150
+// registers, three waves' worth; held to 128 it spills about forty of them and is still the faster (more tiles in
+// flight per compute unit: 0.44 -> 0.41 ms on the cornell box, 2.08 -> 1.87 ms on the random spheres, 0.95 -> 0.94 ms on the dragon).
+#ifndef PTK_TILE_WAVES
+#define PTK_TILE_WAVES(blocks) __attribute__((amdgpu_waves_per_eu((blocks) ? 4 : 1, (blocks) ? 4 : 10)))
+#endif
 // One invocation of main(), :1639-1705, including cast_ray, :1553-1635.
-template <bool TRACE, bool EARLY_T>
-__global__ __launch_bounds__(64) void ptk_render_kernel(const PtkParams P) {
+// BLOCKS: the dispatch is known to search through the compiled node blocks only (BVH flag set, no BVH view, blocks
+// present, untraced, no early-t): the kernel then holds that one search and needs fewer registers.
+template <bool TRACE, bool EARLY_T, bool BLOCKS = false>
+__global__ __launch_bounds__(64) PTK_TILE_WAVES(BLOCKS) void ptk_render_kernel(const PtkParams P) {
     extern __shared__ int lds_stack[];
     const int lane = threadIdx.x;
     const int gx = blockIdx.x * 8 + (lane & 7);
@@ -77,7 +85,8 @@ __global__ __launch_bounds__(64) void ptk_render_kernel(const PtkParams P) {
     for (; i < push.max_default_depth + L.refraction_bounces; i++) {
         if (TRACE) cnt[PTK_CNT_RAYS]++;
         Hit h;
-        if (!use_bvh) h = check_ray_hit_all<TRACE>(P, nr, cnt);
+        if (BLOCKS) h = check_ray_hit_blocks(P, nr, S);
+        else if (!use_bvh) h = check_ray_hit_all<TRACE>(P, nr, cnt);
         else if (EARLY_T) h = check_ray_hit_bvh<TRACE, EARLY_T>(P, L, nr, S, ST, cnt);
         else if (!TRACE && P.wf.blocks != nullptr && !show_bvh_view) h = check_ray_hit_blocks(P, nr, S);  // no counters kept
         else h = check_ray_hit_bvh2<TRACE>(P, L, nr, S, cnt);
@@ -140,7 +149,9 @@ extern "C" hipError_t ptk_launch_render(const PtkParams* p, int gx, int gy, int 
         if (early_t) hipLaunchKernelGGL((ptk_render_kernel<true, true>), grid, block, lds_bytes, stream, *p);
         else hipLaunchKernelGGL((ptk_render_kernel<true, false>), grid, block, lds_bytes, stream, *p);
     } else {
+        const bool blocks_only = !early_t && p->push.flags >= 0 && (p->push.flags & 1) && p->push.render_mode != 1 && p->wf.blocks != nullptr;
         if (early_t) hipLaunchKernelGGL((ptk_render_kernel<false, true>), grid, block, lds_bytes, stream, *p);
+        else if (blocks_only) hipLaunchKernelGGL((ptk_render_kernel<false, false, true>), grid, block, lds_bytes, stream, *p);
         else hipLaunchKernelGGL((ptk_render_kernel<false, false>), grid, block, lds_bytes, stream, *p);
     }
     return hipGetLastError();
