@@ -136,6 +136,12 @@ struct ptk_ctx {
     size_t wf_slots = 0;
     int* d_wf_spill = nullptr;
     uint32_t* d_pixel_counter = nullptr;  // persistent renderer: next pixel slot to hand out
+    // one-kernel renderer: per-tile durations of the last dispatch and the order made from them (PtkParams::tile_order)
+    uint32_t* d_tile_cost = nullptr;
+    uint32_t* d_tile_order = nullptr;
+    size_t tile_capacity = 0;
+    int tile_gx = 0, tile_gy = 0;     // group counts the recorded costs belong to (0: none recorded)
+    bool tile_ordering = true;        // (PTK_TILE_ORDER=0 turns it off; read once at create)
     void* d_display = nullptr;     // RGBA8 staging of ptk_image_read_display
     size_t display_bytes = 0;
     size_t wf_spill_ints = 0;
@@ -241,6 +247,7 @@ ptk_ctx* ptk_create(int device_ordinal) {
     if (const char* w = getenv("PTK_LEAF_SPLIT")) ctx->leaf_split = std::max(1, std::min(255, atoi(w)));
     if (const char* w = getenv("PTK_WF_WG_CLAIM")) ctx->wf_wg_claim = std::max(1, std::min(64, atoi(w) / 64)) * 64;
     if (const char* c = getenv("PTK_WF_WAVES_PER_CU")) ctx->waves_per_cu_cap = std::max(1, atoi(c));
+    if (const char* c = getenv("PTK_TILE_ORDER")) ctx->tile_ordering = atoi(c) != 0;
     if (!ok) {
         fail(nullptr, PTK_E_HIP, "stream/event creation failed");
         delete ctx;
@@ -275,6 +282,8 @@ void ptk_destroy(ptk_ctx* ctx) {
     if (ctx->d_wf_spill) (void)hipFree(ctx->d_wf_spill);
     if (ctx->d_wf_carry) (void)hipFree(ctx->d_wf_carry);
     if (ctx->d_pixel_counter) (void)hipFree(ctx->d_pixel_counter);
+    if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
+    if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
     if (ctx->d_display) (void)hipFree(ctx->d_display);
     for (int k = 0; k < 2; k++) {
         if (ctx->h_stage[k]) (void)hipHostFree(ctx->h_stage[k]);
@@ -1366,6 +1375,26 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     if (choice == 0) {
         ctx->wf_iters[slot] = 0;
         HIP_TRY(ctx, hipEventRecord(ctx->ev0[slot], ctx->stream));
+        if (ctx->tile_ordering && !trace && (size_t)groups_x * groups_y >= 8192) {
+            // long tiles first, by what the last dispatch of this grid measured (the order kernel is part of the dispatch's time)
+            const size_t n_tiles = (size_t)groups_x * groups_y;
+            if (n_tiles > ctx->tile_capacity) {
+                if (ctx->d_tile_cost) { (void)hipFree(ctx->d_tile_cost); ctx->d_tile_cost = nullptr; }
+                if (ctx->d_tile_order) { (void)hipFree(ctx->d_tile_order); ctx->d_tile_order = nullptr; }
+                ctx->tile_capacity = 0;
+                ctx->tile_gx = ctx->tile_gy = 0;
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tile_cost, n_tiles * 4));
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tile_order, n_tiles * 4));
+                ctx->tile_capacity = n_tiles;
+            }
+            if (ctx->tile_gx == groups_x && ctx->tile_gy == groups_y) {
+                HIP_TRY(ctx, ptk_launch_tile_order(ctx->d_tile_cost, (uint32_t)n_tiles, ctx->d_tile_order, ctx->stream));
+                P.tile_order = ctx->d_tile_order;
+            }
+            P.tile_cost = ctx->d_tile_cost;
+            ctx->tile_gx = groups_x;
+            ctx->tile_gy = groups_y;
+        }
         HIP_TRY(ctx, ptk_launch_render(&P, groups_x, groups_y, trace, ctx->early_t_break, lds_bytes, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev1[slot], ctx->stream));
         ctx->dispatch_count++;

@@ -139,12 +139,19 @@ struct PtkParams {
     size_t spill_stride;  // lanes in the launch
     int* trace_primary;
     int* trace_counters;
+    // One-kernel renderer: tiles are not all alike (a tile of sky ends at its first search, a tile on a mesh runs
+    // every bounce), and a launch lasts until its last tile is through.  A progressive render repeats the same frame,
+    // so each dispatch records how long every tile took, and the next one starts the long tiles first.
+    const uint32_t* tile_order;  // workgroup -> tile (row-major tile number); null = workgroup number itself
+    uint32_t* tile_cost;         // tile -> ticks of a 100 MHz clock this dispatch spent on it; null = not recorded
     PtkWavefront wf;
     PtkPush push;
 };
 
 extern "C" hipError_t ptk_launch_render(const PtkParams* p, int gx, int gy, int trace, int early_t,
                                         size_t lds_bytes, hipStream_t stream);
+// order[0 .. n) = the tiles sorted by the power of two of their recorded cost, costliest first (one workgroup).
+extern "C" hipError_t ptk_launch_tile_order(const uint32_t* cost, uint32_t n, uint32_t* order, hipStream_t stream);
 // Wavefront renderer: generate, then n_iter x (traverse, shade).  ev[2k], ev[2k+1] (may be null) are
 // recorded around the k-th traversal launch.  n_wgs = persistent traversal workgroups (PTK_WF_WG_WAVES waves each),
 // lds_bytes = their dynamic LDS: n_top * PTK_TOP_BLOCK_STRIDE + PTK_WF_WG_WAVES * (lds_cap + 1) * 256 + PTK_WF_WG_FLAG_BYTES.

@@ -31,8 +31,11 @@ template <bool TRACE, bool EARLY_T, bool BLOCKS = false>
 __global__ __launch_bounds__(64) PTK_TILE_WAVES(BLOCKS) void ptk_render_kernel(const PtkParams P) {
     extern __shared__ int lds_stack[];
     const int lane = threadIdx.x;
-    const int gx = blockIdx.x * 8 + (lane & 7);
-    const int gy = blockIdx.y * 8 + (lane >> 3);
+    const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t tile = P.tile_order ? P.tile_order[wg] : wg;  // (a permutation of the tiles: every pixel is rendered once)
+    const unsigned long long tile_t0 = P.tile_cost ? wall_clock64() : 0ull;
+    const int gx = (int)(tile % gridDim.x) * 8 + (lane & 7);
+    const int gy = (int)(tile / gridDim.x) * 8 + (lane >> 3);
     const PtkPush& push = P.push;
 
     int cnt[PTK_NCOUNTERS];
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(64) PTK_TILE_WAVES(BLOCKS) void ptk_render_kernel(c
 
     Stack S, ST;
     S.lds = lds_stack; S.lane = lane; S.lds_cap = P.lds_cap;
-    const size_t glane = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + lane;
+    const size_t glane = (size_t)wg * 64 + lane;
     S.spill_stride = P.spill_stride;
     S.spill = P.spill ? P.spill + glane : nullptr;
     ST = S;
@@ -141,6 +144,60 @@ __global__ __launch_bounds__(64) PTK_TILE_WAVES(BLOCKS) void ptk_render_kernel(c
             }
         }
     }
+    if (P.tile_cost && lane == 0) {
+        const unsigned long long dt = wall_clock64() - tile_t0;
+        P.tile_cost[tile] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
+    }
+}
+
+// Tiles in the order the next dispatch should start them: by the power of two of the time they took in the last
+// one, the longest first.  A counting sort over 33 classes by one workgroup; a wave places 64 consecutive tiles at
+// a time, so tiles of one class stay in runs of neighbours (which share rays' nodes in the caches), and when all
+// tiles fall into two adjacent classes the frame is even enough to be left in its own order.  The order changes
+// when a tile runs, not what it computes.
+__global__ __launch_bounds__(1024) void ptk_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ order) {
+    __shared__ uint32_t count[33], start[33];
+    __shared__ int even;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 33) count[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) atomicAdd(&count[cost[i] ? 32 - __clz(cost[i]) : 0], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t at = 0;
+        int lo = 33, hi = -1;
+        for (int c = 32; c >= 0; c--) {
+            start[c] = at;
+            at += count[c];
+            if (count[c]) { lo = c; if (hi < 0) hi = c; }
+        }
+        even = hi - lo <= 1;
+    }
+    __syncthreads();
+    if (even) {
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) order[i] = i;
+        return;
+    }
+    for (uint32_t i0 = (threadIdx.x >> 6) * 64; i0 < n; i0 += 1024) {  // (uniform over the wave)
+        const uint32_t i = i0 + lane;
+        const int c = i < n ? (cost[i] ? 32 - __clz(cost[i]) : 0) : -1;
+        unsigned long long todo = __ballot(c >= 0);
+        while (todo) {
+            const int cls = __builtin_amdgcn_readlane(c, __builtin_ctzll(todo));
+            const unsigned long long m = __ballot(c == cls);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&start[cls], (uint32_t)__popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (c == cls) order[base + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = i;
+            todo &= ~m;
+        }
+    }
+}
+
+extern "C" hipError_t ptk_launch_tile_order(const uint32_t* cost, uint32_t n, uint32_t* order, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(ptk_tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, n, order);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t ptk_launch_render(const PtkParams* p, int gx, int gy, int trace, int early_t, size_t lds_bytes, hipStream_t stream) {
