@@ -292,8 +292,11 @@ int ptk_dispatch_traverse_ms(ptk_ctx* ctx, int back, float* ms, int capacity, in
 /* How often the library had to re-validate the bound scene and rebuild its derived structures
  * (full_validations), and how many ptk_buffer_update calls it absorbed by patching them in place
  * (patched_updates): the reference's incremental edits (pt_renderer.gd:664-788: single records, boxes
- * of dirty BVH nodes) are patched; a change of node ids, transform indices or the object-id table
- * makes the next dispatch rebuild.  No counterpart in the reference. */
+ * of dirty BVH nodes) are patched, and so are an object leaving or joining a leaf that has room
+ * (pt_bvh_tree.gd:333-338, 375-385: the leaf's record with another object count over the same id
+ * slots, and writes to those slots of the object-id table, up to 4096 slots a call); any other change
+ * of a node's id or a change of its transform index makes the next dispatch rebuild.  No counterpart
+ * in the reference. */
 int ptk_update_stats(ptk_ctx* ctx, long long* full_validations, long long* patched_updates);
 
 /* Multi-GPU glue; no counterpart in the reference, which renders on one device.  Copies the rgba32f

@@ -810,17 +810,32 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
         }
         return 1;
     }
-    if (o->set == PTK_SET_BVH && o->binding == 0) {  // nodes: boxes may move, ids and transform indices may not
+    if (o->set == PTK_SET_BVH && o->binding == 0) {
+        // nodes: boxes may move; a leaf may change the number of objects it lists (the plugin's remove_object / add_object
+        // on a leaf with room, pt_bvh_tree.gd:333-338, 375-385: the record comes back with another count, the same
+        // first id slot); anything else about an id, and any transform index, changes the topology
         size_t a, b;
         records(32, a, b);
         if (b - a > kMaxPatched || !ctx->wf_ok) return 0;
+        Object* idt = bound_buffer(ctx, PTK_SET_BVH, 1);
+        const int n_ids = idt ? (int)(idt->nbytes / 4) : 0;
         for (size_t i = a; i < b; i++) {
             const size_t lo = std::max(offset, i * 32), hi = std::min(offset + nbytes, i * 32 + 32);
             uint8_t old_rec[32];
             memcpy(old_rec, o->shadow.data() + i * 32, 32);
             memcpy(old_rec + (lo - i * 32), before.data() + (lo - offset), hi - lo);
-            if (memcmp(old_rec + 12, o->shadow.data() + i * 32 + 12, 4) != 0 || memcmp(old_rec + 28, o->shadow.data() + i * 32 + 28, 4) != 0)
-                return 0;  // topology changed
+            if (memcmp(old_rec + 28, o->shadow.data() + i * 32 + 28, 4) != 0) return 0;  // transform index
+            if (memcmp(old_rec + 12, o->shadow.data() + i * 32 + 12, 4) != 0) {
+                int32_t was, now;
+                memcpy(&was, old_rec + 12, 4);
+                memcpy(&now, o->shadow.data() + i * 32 + 12, 4);
+                const int was_idx = sext(was, 0, 24), now_idx = sext(now, 0, 24), now_count = std::abs(sext(now, 24, 8));
+                // a leaf before and after (negative words, as PTBVHTree writes them), same first slot, its slots inside the table
+                if (!(was < 0 && now < 0 && was_idx < 0 && now_idx == was_idx)) return 0;
+                const int base = -now_idx - 1;
+                if (now_count > PTK_MAX_WIDTH * 16 || base < 0 || base + now_count > n_ids) return 0;
+                if (i >= ctx->node_slot.size() || ctx->node_slot[i] < 0) return 0;  // (a root that is a leaf: rebuild)
+            }
         }
         for (size_t i = a; i < b; i++) {
             float box[8];
@@ -833,10 +848,53 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
             float* h = ctx->h_blocks.data() + blk;
             const int plane_of[6] = {0, 1, 2, 4, 5, 6};
             for (int k = 0; k < 6; k++) h[k * 8 + l] = box[plane_of[k]];
+            int32_t id;
+            memcpy(&id, o->shadow.data() + i * 32 + 12, 4);
+            if (id < 0) memcpy(h + 48 + l, &id, 4);  // a leaf's entry in its parent's block is its id word
             const uint32_t bi = (uint32_t)(ns >> 3);
             if (!ctx->block_is_dirty[bi]) { ctx->block_is_dirty[bi] = 1; ctx->dirty_blocks.push_back(bi); }
         }
         derive_chain(ctx);  // a patched box may be one of the chain's
+        return 1;
+    }
+    if (o->set == PTK_SET_BVH && o->binding == 1) {
+        // id table: a slot names another primitive (the ids of a leaf that lost or gained an object are written again):
+        // the slot's leaf record is made anew from that primitive, and the maps from primitives to slots follow
+        if ((offset | nbytes) & 3) return 0;
+        const size_t a = offset / 4, b = (offset + nbytes) / 4;
+        if (b - a > kMaxPatched) return 0;
+        Object* tri = bound_buffer(ctx, PTK_SET_OBJECT, 3);
+        Object* sph = bound_buffer(ctx, PTK_SET_OBJECT, 1);
+        if (!tri || !sph || b > ctx->h_leaf_records_slots || b > ctx->slot_is_dirty.size()) return 0;
+        const int n_tri = (int)(tri->nbytes / 80), n_sph = (int)(sph->nbytes / 32);
+        for (size_t i = a; i < b; i++) {
+            int32_t was, now;
+            memcpy(&was, before.data() + (i * 4 - offset), 4);
+            memcpy(&now, o->shadow.data() + i * 4, 4);
+            if (was == now) continue;
+            const int type = sext(now, 24, 8), oi = sext(now, 0, 24);
+            if (type == 3 ? (oi < 0 || oi >= n_tri) : type == 1 ? (oi < 0 || oi >= n_sph) : false) return 0;  // let validation report it
+            const int wtype = sext(was, 24, 8), woi = sext(was, 0, 24);
+            // the primitive that was listed here: no longer in this slot (one listed twice keeps its mark)
+            if (wtype == 3 && woi >= 0 && (size_t)woi < ctx->tri_slot.size() && ctx->tri_slot[woi] == (int32_t)i) ctx->tri_slot[woi] = -1;
+            if (wtype == 1 && woi >= 0 && (size_t)woi < ctx->sph_slot.size() && ctx->sph_slot[woi] == (int32_t)i) ctx->sph_slot[woi] = -1;
+            float* r = ctx->h_leaf_records.get() + i * 12;
+            memset(r, 0, 48);
+            if (type == 3) {
+                if ((size_t)oi >= ctx->tri_slot.size()) return 0;
+                const uint8_t* p = tri->shadow.data() + (size_t)oi * 80;
+                memcpy(r + 0, p + 0, 12); memcpy(r + 4, p + 16, 12); memcpy(r + 8, p + 32, 12);
+                ctx->tri_slot[oi] = ctx->tri_slot[oi] == -1 ? (int32_t)i : -2;
+                ctx->leaves_hold_triangles = true;
+            } else if (type == 1) {
+                if ((size_t)oi >= ctx->sph_slot.size()) return 0;
+                const uint8_t* p = sph->shadow.data() + (size_t)oi * 32;
+                memcpy(r + 0, p, 12); memcpy(r + 4, p + 12, 4);
+                ctx->sph_slot[oi] = ctx->sph_slot[oi] == -1 ? (int32_t)i : -2;
+            }
+            if (type == 3 || type == 1) memcpy(r + 3, &now, 4);
+            if (!ctx->slot_is_dirty[i]) { ctx->slot_is_dirty[i] = 1; ctx->dirty_slots.push_back((uint32_t)i); }
+        }
         return 1;
     }
     return 0;  // object ids and anything else: rebuild

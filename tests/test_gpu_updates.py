@@ -89,8 +89,11 @@ def test_edits_between_samples(pta, rd, rd_wf, golden_dir, scene_name):
             full, patched = dev.update_stats()
             assert full == full0, "topology-preserving edits must not trigger a full re-validation"
             assert patched > patched0
-        # 5. the object-id table is rewritten (same contents): this one does rebuild
-        apply("object_ids", "object_id_buffer", 0, packed.object_ids[:8])
+        # 5. an inner node loses its last child (its subtree can no longer be reached): the topology changed, this one does rebuild
+        words = np.frombuffer(packed.bvh, np.int32).reshape(-1, 8)
+        inner = next(i for i in range(n_nodes) if words[i, 3] > 0 and (words[i, 3] >> 24) >= 2 and words[i, 7] < 0)
+        idx, count = int(words[inner, 3]) & 0x00FFFFFF, int(words[inner, 3]) >> 24
+        apply("bvh", "bvh_buffer", inner * 32 + 12, struct.pack("<i", idx ^ ((count - 1) << 24)))
         _render_all(pta, devs, packed, scene, win, 3, cpu)
         for (_, dev, _), (full0, _) in zip(devs, base_stats):
             assert dev.update_stats()[0] == full0 + 1
@@ -102,6 +105,77 @@ def test_edits_between_samples(pta, rd, rd_wf, golden_dir, scene_name):
                 d.create_compute_list(win, scene.camera, 0.0, sync=True)
             dev.buffer_update(d.sphere_buffer, 16, 4, packed.spheres[16:20])
             d.create_compute_list(win, scene.camera, 0.0, sync=True)
+    finally:
+        rd.set_renderer(pta.rendering_device.PTK_RENDERER_AUTO)
+        for _, _, d in devs:
+            d.free_rids()
+
+
+@pytest.mark.parametrize("scene_name", ["benchmark_random_scene", "dragon_test"])
+def test_objects_leave_and_join_leaves_between_samples(pta, rd, rd_wf, golden_dir, scene_name):
+    """The plugin's remove_object / add_object on a leaf with room (pt_bvh_tree.gd:333-338, 375-385) as the buffers
+    see them: the leaf's record comes back with another object count (same first id slot), and the ids of its slots
+    are written again.  Both are absorbed by patching -- the parent's block entry, the slots' leaf records -- without
+    a re-validation of the scene, and the image follows the oracle's on the edited bytes."""
+    wd = pta.work_dispatcher
+    scene = pta.scenes.load_fixture_scene(scene_name, golden_dir)
+    packed = copy.copy(wd.pack_scene(scene, ob.OracleBvhBuilder(), 8))
+    w, h = 320, 184
+    devs = []
+    for name, dev in (("one-kernel", rd), (rd_wf.pinned, rd_wf)):
+        d = wd.PTWorkDispatcher(dev)
+        d.create_buffers(w, h, packed=packed)
+        d.load_shader()
+        devs.append((name, dev, d))
+    win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=5, max_refraction_bounces=4)
+    cpu = np.zeros((h, w, 4), np.float32)
+    rd.set_renderer(pta.rendering_device.PTK_RENDERER_SINGLE_KERNEL)
+    try:
+        _render_all(pta, devs, packed, scene, win, 0, cpu)
+        base_stats = [dev.update_stats() for _, dev, _ in devs]
+
+        def apply(field, attr, offset, data):
+            _edit(packed, field, offset, data)
+            for _, dev, d in devs:
+                dev.buffer_update(getattr(d, attr), offset, len(data), data)
+
+        words = np.frombuffer(packed.bvh, np.int32).reshape(-1, 8).copy()
+        ids = np.frombuffer(packed.object_ids, np.int32).copy()
+        leaves = []
+        for i in range(1, words.shape[0]):
+            node_id = int(words[i, 3])
+            if node_id >= 0:
+                continue
+            idx = ((node_id & 0x00FFFFFF) ^ 0x00800000) - 0x00800000          # sign-extended low 24 bits
+            count = abs(((node_id >> 24) & 0xFF ^ 0x80) - 0x80)                # |sign-extended top byte|
+            if idx < 0 and count >= 2:
+                leaves.append((i, -idx - 1, count))
+        leaves = leaves[::max(1, len(leaves) // 24)][:24]
+        assert len(leaves) >= 8
+
+        def leaf_word(base, count):  # PTBVHTree.BVHNode.to_byte_array for a leaf, pt_bvh_tree.gd:931-944
+            v = ((-base - 1) ^ ((count - 1) << 24)) & 0xFFFFFFFF
+            return struct.pack("<I", v)
+
+        # an object leaves each of these leaves: its id goes to the end of the leaf's slots, the others move up, the count drops
+        for node, base, count in leaves:
+            rolled = np.concatenate([ids[base + 1:base + count], ids[base:base + 1]]).astype(np.int32)
+            apply("object_ids", "object_id_buffer", base * 4, rolled.tobytes())
+            apply("bvh", "bvh_buffer", node * 32 + 12, leaf_word(base, count - 1))
+        _render_all(pta, devs, packed, scene, win, 1, cpu)
+        # ... and joins again
+        for node, base, count in leaves:
+            apply("bvh", "bvh_buffer", node * 32 + 12, leaf_word(base, count))
+        _render_all(pta, devs, packed, scene, win, 2, cpu)
+        # a slot is given to another primitive of the scene (an object swapped for another one of the same kind)
+        for node, base, count in leaves[:8]:
+            other = ids[leaves[-1][1]]
+            apply("object_ids", "object_id_buffer", base * 4, struct.pack("<i", int(other)))
+        _render_all(pta, devs, packed, scene, win, 3, cpu)
+        for (_, dev, _), (full0, patched0) in zip(devs, base_stats):
+            full, patched = dev.update_stats()
+            assert full == full0, "objects leaving and joining leaves must be absorbed without re-validating the scene"
+            assert patched >= patched0 + 3 * len(leaves)
     finally:
         rd.set_renderer(pta.rendering_device.PTK_RENDERER_AUTO)
         for _, _, d in devs:
