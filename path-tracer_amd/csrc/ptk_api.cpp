@@ -835,6 +835,17 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
                 const int base = -now_idx - 1;
                 if (now_count > PTK_MAX_WIDTH * 16 || base < 0 || base + now_count > n_ids) return 0;
                 if (i >= ctx->node_slot.size() || ctx->node_slot[i] < 0) return 0;  // (a root that is a leaf: rebuild)
+                // the slots it lists now may never have been reachable: the same test validation makes of a leaf's ids
+                Object* tri = bound_buffer(ctx, PTK_SET_OBJECT, 3);
+                Object* sph = bound_buffer(ctx, PTK_SET_OBJECT, 1);
+                if (!idt || !tri || !sph) return 0;
+                const int n_tri = (int)(tri->nbytes / 80), n_sph = (int)(sph->nbytes / 32);
+                for (int k = 0; k < now_count; k++) {
+                    int32_t oid;
+                    memcpy(&oid, idt->shadow.data() + (size_t)(base + k) * 4, 4);
+                    const int type = sext(oid, 24, 8), oi = sext(oid, 0, 24);
+                    if ((type == 1 && (oi < 0 || oi >= n_sph)) || (type == 3 && (oi < 0 || oi >= n_tri))) return 0;  // let validation report it
+                }
             }
         }
         for (size_t i = a; i < b; i++) {

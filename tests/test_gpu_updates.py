@@ -176,6 +176,19 @@ def test_objects_leave_and_join_leaves_between_samples(pta, rd, rd_wf, golden_di
             full, patched = dev.update_stats()
             assert full == full0, "objects leaving and joining leaves must be absorbed without re-validating the scene"
             assert patched >= patched0 + 3 * len(leaves)
+
+        # a leaf that grows over a slot naming a primitive the scene does not have: reported at the next dispatch, not executed
+        node, base, count = leaves[0]
+        good = bytes(packed.object_ids[(base + count - 1) * 4:(base + count) * 4])
+        for _, dev, d in devs:
+            dev.buffer_update(d.bvh_buffer, node * 32 + 12, 4, leaf_word(base, count - 1))
+            dev.buffer_update(d.object_id_buffer, (base + count - 1) * 4, 4, struct.pack("<I", (3 << 24) | 0x7FFFF0))
+            d.create_compute_list(win, scene.camera, 0.0, sync=True)      # (the slot cannot be reached: a valid scene)
+            dev.buffer_update(d.bvh_buffer, node * 32 + 12, 4, leaf_word(base, count))
+            with pytest.raises(pta.PtkError):
+                d.create_compute_list(win, scene.camera, 0.0, sync=True)
+            dev.buffer_update(d.object_id_buffer, (base + count - 1) * 4, 4, good)
+            d.create_compute_list(win, scene.camera, 0.0, sync=True)
     finally:
         rd.set_renderer(pta.rendering_device.PTK_RENDERER_AUTO)
         for _, _, d in devs:
