@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 cd $R
 timeout -k 10 400 python3 -u bench.py > gpurun_out/${tag}_bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_trace -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${tag}_bench_under_rocprof.json 2> $R/gpurun_out/${tag}_rocprof.log
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_trace -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-configs > $R/gpurun_out/${tag}_bench_under_rocprof.json 2> $R/gpurun_out/${tag}_rocprof.log
 cp $R/gpurun_out/${tag}_trace/t_kernel_stats.csv $R/gpurun_out/${tag}_kernel_stats.csv
 rm -f $R/gpurun_out/${tag}_trace/t_kernel_trace.csv
 cd $R
