@@ -1452,7 +1452,7 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
                 if (ctx->d_tile_order) { (void)hipFree(ctx->d_tile_order); ctx->d_tile_order = nullptr; }
                 ctx->tile_capacity = 0;
                 ctx->tile_gx = ctx->tile_gy = 0;
-                HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tile_cost, n_tiles * 4));
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tile_cost, n_tiles * 4 * 3));  // (measurement builds keep two more words a tile)
                 HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tile_order, n_tiles * 4));
                 ctx->tile_capacity = n_tiles;
             }
@@ -1672,6 +1672,19 @@ int ptk_dev_wf_ends(ptk_ctx* ctx, unsigned long long* out, size_t n) {
     return PTK_OK;
 }
 #endif
+
+// Development aid (not declared in ptk.h): the tile kernel's per-tile durations of its last dispatch, in ticks of
+// the 100 MHz wall clock; *n = number of tiles (0 when no dispatch recorded any).
+extern "C" int ptk_dev_tile_costs(ptk_ctx* ctx, uint32_t* out, size_t capacity, size_t* n) {
+    if (!ctx || !n) return PTK_E_INVALID;
+    const size_t tiles = ctx->d_tile_cost ? (size_t)ctx->tile_gx * ctx->tile_gy : 0;
+    *n = tiles;
+    if (!out || capacity < tiles || tiles == 0) return PTK_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->d_tile_cost, (capacity >= 3 * tiles ? 3 : 1) * tiles * 4, hipMemcpyDeviceToHost));
+    return PTK_OK;
+}
 
 int ptk_update_stats(ptk_ctx* ctx, long long* full_validations, long long* patched_updates) {
     if (!ctx || !full_validations || !patched_updates) return PTK_E_INVALID;

@@ -147,6 +147,11 @@ __global__ __launch_bounds__(64) PTK_TILE_WAVES(BLOCKS) void ptk_render_kernel(c
     if (P.tile_cost && lane == 0) {
         const unsigned long long dt = wall_clock64() - tile_t0;
         P.tile_cost[tile] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
+#ifdef PTK_TILE_HWID  // measurement builds: where and when the tile ran (the cost array has room for three words a tile)
+        const uint32_t n_tiles = gridDim.x * gridDim.y;
+        P.tile_cost[n_tiles + tile] = (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) & 0xFFFFu) | (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16);
+        P.tile_cost[2 * n_tiles + tile] = (uint32_t)tile_t0;
+#endif
     }
 }
 
