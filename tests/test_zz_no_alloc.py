@@ -146,7 +146,10 @@ def test_noalloc_error_paths(pta, golden_dir):
             dev.compute_list_dispatch_noalloc(push, 8, 8, 1)
         dev.compute_list_dispatch(push, 8, 8, 1)
         dev.compute_list_dispatch_noalloc(push, 8, 8, 1)
-        dev.buffer_update(d.object_id_buffer, 0, 8, packed.object_ids[:8])  # an edit that needs a rebuild
+        # an edit that needs a rebuild: a node's transform index changes (and is set back, so the scene stays what it was)
+        node0 = bytes(packed.bvh[:32])
+        dev.buffer_update(d.bvh_buffer, 0, 32, node0[:28] + (5).to_bytes(4, "little"))
+        dev.buffer_update(d.bvh_buffer, 0, 32, node0)
         with pytest.raises(pta.PtkError, match="ptk_dispatch once"):
             dev.compute_list_dispatch_noalloc(push, 8, 8, 1)
         dev.compute_list_dispatch(push, 8, 8, 1)
