@@ -1300,6 +1300,8 @@ static void fill_blocks(const ptk_ctx* ctx, PtkParams& P) {
     P.wf.n_top = ctx->n_top;
     P.wf.n_chain = ctx->n_chain;
     memcpy(P.wf.chain, ctx->chain, sizeof P.wf.chain);
+    P.wf.chain_xf = -1;
+    for (int k = 0; k < ctx->n_chain; k++) if (ctx->chain[k].kind == 1) P.wf.chain_xf = ctx->chain[k].xf;
     P.wf.n_blocks = ctx->n_blocks; P.wf.n_sockets = ctx->n_sockets; P.wf.n_records = ctx->n_records;
     // leaves longer than this are shared with a helper lane: worth its set-up for triangle tests, not for sphere tests
     P.wf.leaf_split = ctx->leaves_hold_triangles ? ctx->leaf_split : 255;
@@ -1506,7 +1508,7 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     if (n_slots > ctx->wf_slots) {
         if (ctx->d_wf) { (void)hipFree(ctx->d_wf); ctx->d_wf = nullptr; }
         ctx->wf_slots = 0;
-        const size_t per_slot = 2 * 32 + 2 * 32 + 16 + 8 + 40;  // rays x2, state x2, hits, hit uv, inside arrays
+        const size_t per_slot = 2 * 32 + 2 * 32 + 16 + 8 + 40 + 2 * PTK_WF_PREP_PLANES * 4;  // rays x2, state x2, hits, hit uv, inside arrays, started searches x2
         HIP_TRY(ctx, hipMalloc(&ctx->d_wf, n_slots * per_slot + 1024));
         ctx->wf_slots = n_slots;
     }
@@ -1523,7 +1525,10 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         P.wf.state[1] = (float4*)base; base += cap * 32;
         P.wf.hits = (int4*)base; base += cap * 16;
         P.wf.hit_uv = (float2*)base; base += cap * 8;
-        P.wf.inside = (int*)base;
+        P.wf.inside = (int*)base; base += cap * 40;
+        P.wf.prep[0] = (uint32_t*)base; base += cap * PTK_WF_PREP_PLANES * 4;
+        P.wf.prep[1] = (uint32_t*)base;
+        P.wf.prep_cap = (uint32_t)cap;
         P.wf.n_slots = (uint32_t)n_slots;
         P.wf.tiles_x = groups_x;
     }

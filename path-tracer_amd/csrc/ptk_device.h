@@ -50,6 +50,7 @@ struct PtkTexDesc {
 #endif
 #define PTK_WF_WG_FLAG_BYTES 16 // LDS words the waves of a workgroup share besides the top blocks: queue dry, waves done, the claim word (wg_claim)
 #define PTK_WF_CARRY_PLANES 25 // words of search state carried besides the stack rows
+#define PTK_WF_PREP_PLANES 10  // words of a started search (PtkWavefront::prep; wf_prepare in ptk_wavefront.hip)
 // The top of many trees is a chain every ray walks in the same way: a root with one child, a mesh socket, a
 // mesh root with one child (scene root -> PTMesh socket -> mesh tree is the plugin's usual layout).  Those
 // steps need no per-lane node fetch: the host lists them here (they travel as kernel arguments) and every
@@ -87,6 +88,13 @@ struct PtkWavefront {
     int32_t leaf_split;  // a leaf of more objects than this is split between its lane and a helper lane (255: never)
     int32_t leaf_redo_all;  // test switch: every helped leaf is handed back to its owner, as if its helper had met the sphere corner
     uint32_t wg_claim;   // queue entries a traversal workgroup takes from the device-wide counter at a time (a multiple of 64)
+    // A search's start -- planes, root box, the chain of one-child nodes and mesh sockets at the top of the tree -- is run
+    // by the kernel that queues the ray (generate, shade), where all 64 lanes of a wave have one, instead of in the
+    // traversal kernel's refill rounds, where a dozen lanes do: prep[parity] holds the started search of every queue
+    // entry as planes [word][prep_cap] (PTK_WF_PREP_PLANES words, see wf_prepare).
+    uint32_t* prep[2];
+    uint32_t prep_cap;
+    int32_t chain_xf;  // transform index of the mesh socket among the chain's steps (at most one: a mesh tree holds none), -1 if none
     float4* state[2];  // path state travelling with the queue entry, two float4 per entry:
                        // {throughput rgba}, {seed, current_IOR, bits(inside_of_count),
                        //  bits(refraction_bounces | inside-arrays-stored << 30)}

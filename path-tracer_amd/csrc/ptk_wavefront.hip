@@ -110,6 +110,48 @@ extern "C" hipError_t ptk_wf_ends_fetch(unsigned long long* out, size_t n, hipSt
 }
 #endif
 
+// The start of the search of queue entry `at` (world ray o, d over [0, inf)): planes, root box and the chain at the top
+// of the tree (trav_begin), run where the ray is queued and left in PtkWavefront::prep for the traversal kernel.
+// Ten words: the ray as the search goes on with it (mesh-local once the chain has entered a mesh), its end, |M d|,
+// the plane hit so far (object id, 0 = none: a plane's id has its type in the top byte) and two flags: bit 0 the search
+// goes on at PtkWavefront::root_entry (else it is over already), bit 1 it is inside the chain's mesh.  What is left of
+// trav_begin's outcome follows from these: start = 0 (times |M d| in a mesh), 1 / d, the world ray = the queue entry's.
+PTK_DEV void wf_prepare(const PtkParams& P, int parity, uint32_t at, f3 o, f3 d) {
+    Ray wr;
+    wr.o = o; wr.d = d; wr.start = 0.0f; wr.end = PT_INF;
+    Trav T;
+    T.w_o = o; T.w_d = d; T.w_start = 0.0f;
+    trav_begin(P, T, wr);
+    uint32_t* c = P.wf.prep[parity] + at;
+    const size_t cap = P.wf.prep_cap;
+    const uint32_t w[PTK_WF_PREP_PLANES] = {
+        fbits(T.o.x), fbits(T.o.y), fbits(T.o.z), fbits(T.d.x), fbits(T.d.y), fbits(T.d.z), fbits(T.end), fbits(T.dir_len),
+        T.h.hit ? (uint32_t)T.h.object_id : 0u, (T.cur != ENTRY_NONE ? 1u : 0u) | (T.cur_xf >= 0 ? 2u : 0u)};
+#pragma unroll
+    for (int k = 0; k < PTK_WF_PREP_PLANES; k++) c[(size_t)k * cap] = w[k];
+}
+// ... and taken up by a lane of the traversal kernel (a, b: the queue entry, whose ray is the search's world ray).
+PTK_DEV void wf_take_prepared(const PtkWavefront& W, Trav& T, int parity, uint32_t at, float4 a, float4 b) {
+    const uint32_t* c = W.prep[parity] + at;
+    const size_t cap = W.prep_cap;
+    uint32_t w[PTK_WF_PREP_PLANES];
+#pragma unroll
+    for (int k = 0; k < PTK_WF_PREP_PLANES; k++) w[k] = c[(size_t)k * cap];
+    T.o = mk3(bitsf(w[0]), bitsf(w[1]), bitsf(w[2]));
+    T.d = mk3(bitsf(w[3]), bitsf(w[4]), bitsf(w[5]));
+    T.inv = mk3(1.0f / T.d.x, 1.0f / T.d.y, 1.0f / T.d.z);
+    T.end = bitsf(w[6]);
+    T.dir_len = bitsf(w[7]);
+    const bool in_mesh = (w[9] & 2u) != 0;
+    T.start = in_mesh ? 0.0f * T.dir_len : 0.0f;  // (trav_enter_mesh_m: the world ray's start, 0, times |M d|)
+    T.h.hit = w[8] != 0u ? 1 : 0; T.h.object_id = (int)w[8]; T.h.transform_index = -1; T.h.u = 0.0f; T.h.v = 0.0f;
+    T.cur = (w[9] & 1u) ? W.root_entry : ENTRY_NONE;
+    T.sp = 0; T.sub_base = 0;
+    T.cur_xf = in_mesh ? W.chain_xf : -1;
+    T.w_o = mk3(a.x, a.y, a.z); T.w_d = mk3(b.x, b.y, b.z);
+    T.w_start = 0.0f;
+}
+
 __global__ __launch_bounds__(64) void ptk_wf_generate(const PtkParams P) {
     const PtkWavefront& W = P.wf;
     const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
@@ -121,6 +163,7 @@ __global__ __launch_bounds__(64) void ptk_wf_generate(const PtkParams P) {
     W.rays[0][(size_t)slot * 2 + 1] = make_float4(pr.ray.d.x, pr.ray.d.y, pr.ray.d.z, 0.0f);
     W.state[0][(size_t)slot * 2] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     W.state[0][(size_t)slot * 2 + 1] = make_float4(pr.seed, 1.0f, bitsf(0u), bitsf(0u));
+    wf_prepare(P, 0, slot, pr.ray.o, pr.ray.d);
 }
 
 // Parking a search that is under way (see PtkWavefront::carry) and taking it up again.  Everything a Trav holds
@@ -269,14 +312,9 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
                 if (!have && my < avail) {
                     ray_idx = c_next + my;
                     const float4 a = rq[(size_t)ray_idx * 2], b = rq[(size_t)ray_idx * 2 + 1];
-                    Ray wr;
-                    wr.o = mk3(a.x, a.y, a.z);
-                    wr.d = mk3(b.x, b.y, b.z);
-                    wr.start = 0.0f;
-                    wr.end = PT_INF;
                     ray_bounce = (int)fbits(b.w);
                     if (ray_idx < n_res) wf_unpark(W, S, T, iter & 1, ray_idx);
-                    else trav_begin(P, T, wr);
+                    else wf_take_prepared(W, T, iter & 1, ray_idx, a, b);
                     have = true;
                 }
                 const uint32_t wanted = (uint32_t)__popcll(need);
@@ -476,6 +514,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(6))
     sout[(size_t)pos * 2] = new_color;
     sout[(size_t)pos * 2 + 1] = make_float4(L.seed, L.current_IOR, bitsf((uint32_t)L.inside_of_count),
                                             bitsf((uint32_t)((L.refraction_bounces & 0x3FFFFFFF) | (store_inside ? (1 << 30) : 0))));
+    wf_prepare(P, (iter + 1) & 1, pos, nr.o, nr.d);
 }
 
 extern "C" hipError_t ptk_wavefront_occupancy(size_t lds_bytes, int* wgs_per_cu) {
