@@ -1678,6 +1678,16 @@ int ptk_dev_wf_ends(ptk_ctx* ctx, unsigned long long* out, size_t n) {
 }
 #endif
 
+// Development aid (not declared in ptk.h): the pipeline's queue counters after its last dispatch: 65 words of counts
+// (rays queued for launch i), 65 of heads (rays handed out), then n_resume (searches parked for launch i).
+extern "C" int ptk_dev_wf_counts(ptk_ctx* ctx, uint32_t* out256) {
+    if (!ctx || !out256 || !ctx->d_wf) return PTK_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out256, ctx->d_wf, 1024, hipMemcpyDeviceToHost));
+    return PTK_OK;
+}
+
 // Development aid (not declared in ptk.h): the tile kernel's per-tile durations of its last dispatch, in ticks of
 // the 100 MHz wall clock; *n = number of tiles (0 when no dispatch recorded any).
 extern "C" int ptk_dev_tile_costs(ptk_ctx* ctx, uint32_t* out, size_t capacity, size_t* n) {

@@ -275,10 +275,11 @@ PTK_DEV int st_read(const Stack& s, int i) {
 // with one 64-bit store; waves that come past the end meanwhile try again at their next refill round.  The
 // wave that finds the device-wide counter past `count` leaves that as a mark in the word.
 enum : int { CLAIM_OK = 0, CLAIM_LATER = 1, CLAIM_DRY = 2 };
-PTK_DEV int wg_claim(unsigned long long* range, uint32_t* head, uint32_t wg_chunk, uint32_t count, int lane, uint32_t& c_next, uint32_t& c_end) {
+// `grab` (at most 64, a divisor of wg_chunk) is what a wave takes at a time.
+PTK_DEV int wg_claim(unsigned long long* range, uint32_t* head, uint32_t wg_chunk, uint32_t count, int lane, uint32_t& c_next, uint32_t& c_end, uint32_t grab = 64u) {
     uint32_t nx = 0, en = 0;
     if (lane == 0) {
-        const unsigned long long old = __hip_atomic_fetch_add(range, 64ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned long long old = __hip_atomic_fetch_add(range, (unsigned long long)grab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         nx = (uint32_t)old; en = (uint32_t)(old >> 32);
     }
     nx = __builtin_amdgcn_readfirstlane(nx);
@@ -293,7 +294,7 @@ PTK_DEV int wg_claim(unsigned long long* range, uint32_t* head, uint32_t wg_chun
             if (lane == 0) __hip_atomic_store(range, 0x80000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             return CLAIM_DRY;
         }
-        if (lane == 0) __hip_atomic_store(range, ((unsigned long long)(base + wg_chunk) << 32) | (unsigned long long)(base + 64u),
+        if (lane == 0) __hip_atomic_store(range, ((unsigned long long)(base + wg_chunk) << 32) | (unsigned long long)(base + grab),
                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         nx = base;
     } else if (nx > en) {
@@ -301,7 +302,7 @@ PTK_DEV int wg_claim(unsigned long long* range, uint32_t* head, uint32_t wg_chun
     }
     if (nx >= count) return CLAIM_DRY;
     c_next = nx;
-    c_end = nx + 64u < count ? nx + 64u : count;
+    c_end = nx + grab < count ? nx + grab : count;
     return CLAIM_OK;
 }
 

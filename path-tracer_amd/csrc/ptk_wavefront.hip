@@ -228,7 +228,11 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
     const uint32_t count = n_res + __builtin_amdgcn_readfirstlane(W.counts[iter]);
     // A queue with no more than one chunk for every workgroup is dealt out by position, without the device-wide counter
     const bool dealt = count <= gridDim.x * W.wg_claim;
-    if (count == 0 || (dealt && blockIdx.x * W.wg_claim >= count)) {  // nothing for this workgroup
+    // ... and evenly: every wave of the launch gets its share (a short queue holds the searches that are left over, long ones;
+    // what a wave runs side by side takes turns in its rounds, so a search among few is through sooner than among 64)
+    const uint32_t grab = dealt ? (count + gridDim.x * PTK_WF_WG_WAVES - 1) / (gridDim.x * PTK_WF_WG_WAVES) : 64u;
+    const uint32_t chunk = dealt ? grab * PTK_WF_WG_WAVES : W.wg_claim;
+    if (count == 0 || (dealt && blockIdx.x * chunk >= count)) {  // nothing for this workgroup
 #ifdef PTK_WF_ENDS
         if (lane == 0 && iter < PTK_WF_ENDS_ITERS) g_wf_ends[ends_at + 1] = wall_clock64();
 #endif
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
             top[(i >> 4) * (PTK_TOP_BLOCK_STRIDE / 16) + (i & 15u)] = W.blocks[i];
         if (threadIdx.x < PTK_WF_WG_FLAG_BYTES / 4) {
             int v = 0;
-            if (dealt && threadIdx.x >= 2) v = (int)((blockIdx.x + (threadIdx.x - 2)) * W.wg_claim);  // [2] next = the chunk's start, [3] its end
+            if (dealt && threadIdx.x >= 2) v = (int)((blockIdx.x + (threadIdx.x - 2)) * chunk);  // [2] next = the chunk's start, [3] its end
             lds_all[W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64 + threadIdx.x] = v;
         }
         __syncthreads();  // the only workgroup-wide step: from here on every wave runs on its own
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
                 const unsigned long long need = __ballot(!have);
                 if (need == 0ull) break;
                 if (c_next == c_end) {
-                    const int got = wg_claim(wg_range, dealt ? nullptr : W.heads + iter, W.wg_claim, count, lane, c_next, c_end);
+                    const int got = wg_claim(wg_range, dealt ? nullptr : W.heads + iter, chunk, count, lane, c_next, c_end, grab);
                     if (got == CLAIM_DRY) { exhausted = true; if (lane == 0) wg_flags[0] = 1; break; }
                     if (got == CLAIM_LATER) { __builtin_amdgcn_s_sleep(1); break; }  // another wave is fetching the workgroup's next chunk
                 }
