@@ -95,6 +95,11 @@ struct ptk_ctx {
     uint32_t root_entry = 0;
     uint32_t n_blocks = 0, n_sockets = 0, n_records = 0;
     bool leaves_hold_triangles = false;  // any triangle in the id table (decides whether long leaves are split, see trav_leaf)
+    // Whether any path can gain refraction bounces (ray_tracer.comp:1476, 1519: only a hit on a material with opacity < 1,
+    // or on material 0, the medium a path starts in, extends the bounce loop).  mat_used marks the materials of the
+    // primitives the id table and the live planes name; marks are only ever added between two validations.
+    std::vector<uint8_t> mat_used;
+    bool may_refract = true;
     // host mirrors and maps of the derived structures, for patching them on buffer_update
     std::vector<float> h_blocks;
     std::unique_ptr<float[]> h_leaf_records;  // 12 floats per object-id slot; only slots patched since the last validation are set
@@ -753,6 +758,22 @@ static int flush_updates(ptk_ctx* ctx) {
     return PTK_OK;
 }
 
+static void mark_material_used(ptk_ctx* ctx, int32_t m) {
+    if (m >= 0 && (size_t)m < ctx->mat_used.size()) ctx->mat_used[m] = 1;
+    else ctx->may_refract = true;  // (an index validation will refuse; nothing to conclude from it)
+}
+static void refresh_may_refract(ptk_ctx* ctx) {
+    Object* mats = bound_buffer(ctx, PTK_SET_OBJECT, 0);
+    bool any = !mats || ctx->mat_used.empty() || ctx->mat_used[0] != 0;
+    for (size_t m = 0; !any && m < ctx->mat_used.size(); m++) {
+        if (!ctx->mat_used[m] || (m + 1) * 64 > mats->shadow.size()) continue;
+        float opacity;
+        memcpy(&opacity, mats->shadow.data() + m * 64 + 20, 4);
+        any = opacity < 1.0f;
+    }
+    ctx->may_refract = any;
+}
+
 // The incremental edit path (pt_renderer.gd:664-788 updates single records and the boxes of dirty BVH
 // nodes with rd.buffer_update).  When the derived structures are current and an update keeps the tree's
 // topology, they are patched in place instead of being rebuilt: leaf records of the touched primitives,
@@ -770,7 +791,7 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
         last = (offset + nbytes + rec_bytes - 1) / rec_bytes;  // exclusive
         last = std::min(last, o->nbytes / rec_bytes);
     };
-    if (o->set == PTK_SET_OBJECT && o->binding == 0) return 1;  // materials: nothing is derived from their contents
+    if (o->set == PTK_SET_OBJECT && o->binding == 0) { refresh_may_refract(ctx); return 1; }  // materials: only whether paths can refract
     if (o->set == PTK_SET_TRANSFORM) { derive_chain(ctx); return 1; }  // (a chain step holds its matrix by value)
     if (o->set == PTK_SET_TRIANGLE || o->set == PTK_SET_TEXTURE) return 1;
     if (o->set == PTK_SET_OBJECT && o->binding == 2) {  // planes
@@ -779,7 +800,9 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
         for (size_t i = a; i < b; i++) {
             int32_t m; memcpy(&m, o->shadow.data() + i * 32 + 16, 4);
             if (m < 0 || m >= n_mats) return 0;  // let validation report it
+            mark_material_used(ctx, m);
         }
+        refresh_may_refract(ctx);
         int r = refresh_live_planes(ctx, o);
         return r == PTK_OK ? 1 : r;
     }
@@ -793,6 +816,7 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
         for (size_t i = a; i < b; i++) {
             int32_t m; memcpy(&m, o->shadow.data() + i * rec + (tri ? 64 : 16), 4);
             if (m < 0 || m >= n_mats) return 0;
+            mark_material_used(ctx, m);
             if (i >= slot_of.size()) return 0;
             const int32_t slot = slot_of[i];
             if (slot == -1) continue;  // not in any leaf
@@ -808,6 +832,7 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
             memcpy(r + 3, &oid, 4);
             if (!ctx->slot_is_dirty[slot]) { ctx->slot_is_dirty[slot] = 1; ctx->dirty_slots.push_back((uint32_t)slot); }
         }
+        refresh_may_refract(ctx);
         return 1;
     }
     if (o->set == PTK_SET_BVH && o->binding == 0) {
@@ -895,17 +920,20 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
                 if ((size_t)oi >= ctx->tri_slot.size()) return 0;
                 const uint8_t* p = tri->shadow.data() + (size_t)oi * 80;
                 memcpy(r + 0, p + 0, 12); memcpy(r + 4, p + 16, 12); memcpy(r + 8, p + 32, 12);
+                { int32_t m; memcpy(&m, p + 64, 4); mark_material_used(ctx, m); }
                 ctx->tri_slot[oi] = ctx->tri_slot[oi] == -1 ? (int32_t)i : -2;
                 ctx->leaves_hold_triangles = true;
             } else if (type == 1) {
                 if ((size_t)oi >= ctx->sph_slot.size()) return 0;
                 const uint8_t* p = sph->shadow.data() + (size_t)oi * 32;
                 memcpy(r + 0, p, 12); memcpy(r + 4, p + 12, 4);
+                { int32_t m; memcpy(&m, p + 16, 4); mark_material_used(ctx, m); }
                 ctx->sph_slot[oi] = ctx->sph_slot[oi] == -1 ? (int32_t)i : -2;
             }
             if (type == 3 || type == 1) memcpy(r + 3, &now, 4);
             if (!ctx->slot_is_dirty[i]) { ctx->slot_is_dirty[i] = 1; ctx->dirty_slots.push_back((uint32_t)i); }
         }
+        refresh_may_refract(ctx);
         return 1;
     }
     return 0;  // object ids and anything else: rebuild
@@ -1135,16 +1163,28 @@ static int validate_scene(ptk_ctx* ctx) {
     ctx->tri_slot.assign((size_t)n_tri, -1);
     ctx->sph_slot.assign((size_t)n_sph, -1);
     ctx->leaves_hold_triangles = false;
+    ctx->mat_used.assign((size_t)n_mats, 0);
     for (int i = 0; i < n_ids; i++) {
         const int oid = idp[i];
         const int type = sext(oid, 24, 8), oi = sext(oid, 0, 24);
         if (type == 3 && oi >= 0 && oi < n_tri) {
             ctx->leaves_hold_triangles = true;
             ctx->tri_slot[oi] = ctx->tri_slot[oi] == -1 ? i : -2;  // -2: listed more than once
+            int32_t m; memcpy(&m, tri->shadow.data() + (size_t)oi * 80 + 64, 4);
+            ctx->mat_used[m] = 1;  // (in range: checked for every record above)
         } else if (type == 1 && oi >= 0 && oi < n_sph) {
             ctx->sph_slot[oi] = ctx->sph_slot[oi] == -1 ? i : -2;
+            int32_t m; memcpy(&m, sph->shadow.data() + (size_t)oi * 32 + 16, 4);
+            ctx->mat_used[m] = 1;
         }
     }
+    for (int i = 0; i < n_pln; i++) {  // planes are tested outside the tree: every record that can be hit
+        float nrm[3]; int32_t m;
+        memcpy(nrm, pln->shadow.data() + (size_t)i * 32, 12);
+        memcpy(&m, pln->shadow.data() + (size_t)i * 32 + 16, 4);
+        if (!(nrm[0] == 0.0f && nrm[1] == 0.0f && nrm[2] == 0.0f)) ctx->mat_used[m] = 1;
+    }
+    refresh_may_refract(ctx);
     if (n_slots > ctx->d_leaf_records_slots) {
         if (ctx->d_leaf_records) { (void)hipFree(ctx->d_leaf_records); ctx->d_leaf_records = nullptr; }
         ctx->d_leaf_records_slots = 0;
@@ -1389,8 +1429,10 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
     // Which schedule renders this dispatch.  The wavefront pipeline and the persistent path kernel cover
     // the plain render mode over the BVH; BVH/normal views, brute force, the early-t variant and traced
     // dispatches use the one-kernel renderer.  All three give the same image.
-    const int rb_max = std::max(P.push.max_refraction_bounces - 1, 0);
-    const int n_iter = P.push.max_default_depth + rb_max;  // most bounces any path can take (ray_tracer.comp:1572)
+    // most bounces any path can take (ray_tracer.comp:1572): the depth limit plus the refraction bounces a path can
+    // collect, which are none where no primitive that can be hit has a material that refracts or is passed through
+    const int rb_max = ctx->may_refract ? std::max(P.push.max_refraction_bounces - 1, 0) : 0;
+    const int n_iter = P.push.max_default_depth + rb_max;
     const bool pp_eligible = persistent_covers(ctx, P.push, trace != 0);
     const bool wf_eligible = pp_eligible && ctx->wf_wgs_per_cu > 0 && n_iter <= PTK_WF_MAX_ITER;  // the pipeline launches once per bounce
     int choice = 0;  // 0 one-kernel renderer, 1 wavefront pipeline, 2 persistent path kernel

@@ -247,3 +247,42 @@ def test_buffers_grow_with_the_scene(pta, golden_dir):
         disp.free_rids()
     finally:
         dev.close()
+
+
+def test_launches_follow_the_materials(pta, golden_dir):
+    """The pipeline launches once per bounce a path can take.  The bounce loop's bound grows with a path's refraction
+    bounces (ray_tracer.comp:1476, 1519, 1573), which only a hit on a material with opacity < 1 (or on material 0)
+    can raise: a scene without such a material among its primitives is rendered with max_default_depth launches,
+    and a material edit that brings one back brings the launches back with it.  Same image as the oracle's each time."""
+    wd = pta.work_dispatcher
+    scene = pta.scenes.load_fixture_scene("sphere_scene1", golden_dir)
+    packed = copy.copy(wd.pack_scene(scene, ob.OracleBvhBuilder(), 8))
+    w, h = 320, 184
+    dev = pta.PtkRenderingDevice(0)
+    try:
+        dev.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
+        d = wd.PTWorkDispatcher(dev)
+        d.create_buffers(w, h, packed=packed)
+        d.load_shader()
+        win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=5, max_refraction_bounces=4)
+        cpu = np.zeros((h, w, 4), np.float32)
+        devs = [("pipeline", dev, d)]
+        _render_all(pta, devs, packed, scene, win, 0, cpu)
+        assert len(dev.dispatch_traverse_ms(0)) == 5 + 3  # the scene has glass
+        n_mats = len(packed.materials) // 64
+        glass = [m for m in range(1, n_mats) if struct.unpack_from("<f", packed.materials, m * 64 + 20)[0] < 1.0]
+        assert glass
+        for m in glass:  # every material opaque
+            data = struct.pack("<f", 1.0)
+            _edit(packed, "materials", m * 64 + 20, data)
+            dev.buffer_update(d.material_buffer, m * 64 + 20, 4, data)
+        _render_all(pta, devs, packed, scene, win, 1, cpu)
+        assert len(dev.dispatch_traverse_ms(0)) == 5
+        data = struct.pack("<f", 0.25)  # and one of them glass again
+        _edit(packed, "materials", glass[0] * 64 + 20, data)
+        dev.buffer_update(d.material_buffer, glass[0] * 64 + 20, 4, data)
+        _render_all(pta, devs, packed, scene, win, 2, cpu)
+        assert len(dev.dispatch_traverse_ms(0)) == 5 + 3
+        d.free_rids()
+    finally:
+        dev.close()
