@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -90,6 +91,7 @@ struct ptk_ctx {
     int last_choice = -1;          // schedule of the last dispatch: 0 one-kernel renderer, 1 pipeline, 2 persistent kernel
     bool wf_ok = false;            // scene has no mesh socket below another mesh socket
     float4* d_blocks = nullptr;    // compiled inner nodes, 256 bytes each (see PtkWavefront)
+    size_t d_blocks_bytes = 0, d_sockets_bytes = 0;  // allocated sizes of d_blocks / d_sockets
     int2* d_sockets = nullptr;
     float root_box[6] = {0};
     uint32_t root_entry = 0;
@@ -100,6 +102,17 @@ struct ptk_ctx {
     // primitives the id table and the live planes name; marks are only ever added between two validations.
     std::vector<uint8_t> mat_used;
     bool may_refract = true;
+    // Validation and derivation on the device (ptk_derive.hip): -1 for trees of 4096 nodes or more, 0 never, 1 always
+    // (PTK_DEVICE_DERIVE, read once at create).  The maps the patches of single edits need -- blocks, socket table,
+    // node -> child slot, primitive -> id slot -- then stay on the device until the first such edit asks for them.
+    int device_derive = -1;
+    void* d_derive = nullptr;
+    size_t derive_bytes = 0;
+    bool mirrors_partial = false;  // h_blocks / h_sockets hold only their first rows, node_slot / tri_slot / sph_slot nothing
+    const int32_t* d_node_slot = nullptr; const int32_t* d_tri_slot = nullptr; const int32_t* d_sph_slot = nullptr;
+    int derive_levels = 0;         // levels of the tree the last device pass walked (0: the host walked)
+    long long device_derivations = 0;
+    double last_validate_ms = 0.0; // host time of the last validate_scene
     // host mirrors and maps of the derived structures, for patching them on buffer_update
     std::vector<float> h_blocks;
     std::unique_ptr<float[]> h_leaf_records;  // 12 floats per object-id slot; only slots patched since the last validation are set
@@ -246,6 +259,7 @@ ptk_ctx* ptk_create(int device_ordinal) {
     const int max_window = (int)((PTK_LDS_BYTES_PER_CU - PTK_WF_WG_FLAG_BYTES) / (PTK_WF_WG_WAVES * 256)) - 1;
     if (const char* w = getenv("PTK_LDS_WINDOW")) ctx->lds_window = std::max(8, std::min(max_window, atoi(w)));
     if (const char* w = getenv("PTK_WF_CARRY")) ctx->wf_carry = atoi(w) != 0;
+    if (const char* w = getenv("PTK_DEVICE_DERIVE")) ctx->device_derive = atoi(w) != 0 ? 1 : 0;
     if (const char* w = getenv("PTK_WF_MAX_LAG")) ctx->wf_max_lag = std::max(1, std::min(PTK_WF_MAX_LAG, atoi(w)));
     if (const char* w = getenv("PTK_WF_PARK_BELOW")) ctx->wf_park_below = std::max(1, std::min(64, atoi(w)));
     if (const char* w = getenv("PTK_LEAF_REDO_ALL")) ctx->leaf_redo_all = atoi(w) != 0;
@@ -282,6 +296,7 @@ void ptk_destroy(ptk_ctx* ctx) {
     if (ctx->d_trace_counters) (void)hipFree(ctx->d_trace_counters);
     if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
     if (ctx->d_sockets) (void)hipFree(ctx->d_sockets);
+    if (ctx->d_derive) (void)hipFree(ctx->d_derive);
     if (ctx->d_leaf_records) (void)hipFree(ctx->d_leaf_records);
     if (ctx->d_wf) (void)hipFree(ctx->d_wf);
     if (ctx->d_wf_spill) (void)hipFree(ctx->d_wf_spill);
@@ -758,6 +773,30 @@ static int flush_updates(ptk_ctx* ctx) {
     return PTK_OK;
 }
 
+// The host copies of what a device derivation left on the GPU, fetched when the first edit needs them.
+static int ensure_mirrors(ptk_ctx* ctx) {
+    if (!ctx->mirrors_partial) return PTK_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Object* nodes = bound_buffer(ctx, PTK_SET_BVH, 0);
+    Object* tri = bound_buffer(ctx, PTK_SET_OBJECT, 3);
+    Object* sph = bound_buffer(ctx, PTK_SET_OBJECT, 1);
+    if (!nodes || !tri || !sph) return fail(ctx, PTK_E_STATE, "the bound scene lost a buffer");
+    const size_t n_nodes = nodes->nbytes / 32, n_tri = tri->nbytes / 80, n_sph = sph->nbytes / 32;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->h_blocks.assign((size_t)ctx->n_blocks * 64, 0.0f);
+    ctx->h_sockets.assign((size_t)ctx->n_sockets * 2, 0);
+    ctx->node_slot.assign(n_nodes, -1);
+    ctx->tri_slot.assign(n_tri, -1);
+    ctx->sph_slot.assign(n_sph, -1);
+    if (ctx->n_blocks) HIP_TRY(ctx, hipMemcpy(ctx->h_blocks.data(), ctx->d_blocks, (size_t)ctx->n_blocks * 256, hipMemcpyDeviceToHost));
+    if (ctx->n_sockets) HIP_TRY(ctx, hipMemcpy(ctx->h_sockets.data(), ctx->d_sockets, (size_t)ctx->n_sockets * 8, hipMemcpyDeviceToHost));
+    if (n_nodes) HIP_TRY(ctx, hipMemcpy(ctx->node_slot.data(), ctx->d_node_slot, n_nodes * 4, hipMemcpyDeviceToHost));
+    if (n_tri) HIP_TRY(ctx, hipMemcpy(ctx->tri_slot.data(), ctx->d_tri_slot, n_tri * 4, hipMemcpyDeviceToHost));
+    if (n_sph) HIP_TRY(ctx, hipMemcpy(ctx->sph_slot.data(), ctx->d_sph_slot, n_sph * 4, hipMemcpyDeviceToHost));
+    ctx->mirrors_partial = false;
+    return PTK_OK;
+}
+
 static void mark_material_used(ptk_ctx* ctx, int32_t m) {
     if (m >= 0 && (size_t)m < ctx->mat_used.size()) ctx->mat_used[m] = 1;
     else ctx->may_refract = true;  // (an index validation will refuse; nothing to conclude from it)
@@ -812,6 +851,7 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
         size_t a, b;
         records(rec, a, b);
         if (b - a > kMaxPatched) return 0;
+        { int r = ensure_mirrors(ctx); if (r != PTK_OK) return r; }
         const std::vector<int32_t>& slot_of = tri ? ctx->tri_slot : ctx->sph_slot;
         for (size_t i = a; i < b; i++) {
             int32_t m; memcpy(&m, o->shadow.data() + i * rec + (tri ? 64 : 16), 4);
@@ -842,6 +882,7 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
         size_t a, b;
         records(32, a, b);
         if (b - a > kMaxPatched || !ctx->wf_ok) return 0;
+        { int r = ensure_mirrors(ctx); if (r != PTK_OK) return r; }
         Object* idt = bound_buffer(ctx, PTK_SET_BVH, 1);
         const int n_ids = idt ? (int)(idt->nbytes / 4) : 0;
         for (size_t i = a; i < b; i++) {
@@ -899,6 +940,7 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
         if ((offset | nbytes) & 3) return 0;
         const size_t a = offset / 4, b = (offset + nbytes) / 4;
         if (b - a > kMaxPatched) return 0;
+        { int r = ensure_mirrors(ctx); if (r != PTK_OK) return r; }
         Object* tri = bound_buffer(ctx, PTK_SET_OBJECT, 3);
         Object* sph = bound_buffer(ctx, PTK_SET_OBJECT, 1);
         if (!tri || !sph || b > ctx->h_leaf_records_slots || b > ctx->slot_is_dirty.size()) return 0;
@@ -978,9 +1020,129 @@ static void derive_chain(ptk_ctx* ctx) {
     ctx->root_entry = e;
 }
 
+// Device room for the compiled blocks and the socket table (kept while it is large enough: a scene change then frees
+// and allocates nothing).
+static int reserve_blocks(ptk_ctx* ctx, size_t n_blocks, size_t n_sockets) {
+    const size_t bb = std::max<size_t>(256, n_blocks * 256), sb = std::max<size_t>(8, n_sockets * 8);
+    if (bb > ctx->d_blocks_bytes) {
+        if (ctx->d_blocks) { (void)hipFree(ctx->d_blocks); ctx->d_blocks = nullptr; }
+        ctx->d_blocks_bytes = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_blocks, bb));
+        ctx->d_blocks_bytes = bb;
+    }
+    if (sb > ctx->d_sockets_bytes) {
+        if (ctx->d_sockets) { (void)hipFree(ctx->d_sockets); ctx->d_sockets = nullptr; }
+        ctx->d_sockets_bytes = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sockets, sb));
+        ctx->d_sockets_bytes = sb;
+    }
+    return PTK_OK;
+}
+
+// The top blocks the traversal kernel's LDS has room for beside its stack windows, at this stack need.
+static size_t top_block_limit(const ptk_ctx* ctx, int stack_need) {
+    const size_t stacks = (size_t)PTK_WF_WG_WAVES * (std::min(stack_need, ctx->lds_window) + 1) * 256 + PTK_WF_WG_FLAG_BYTES;
+    const size_t room = PTK_LDS_BYTES_PER_CU > stacks ? (PTK_LDS_BYTES_PER_CU - stacks) / PTK_TOP_BLOCK_STRIDE : 0;
+    return std::min<size_t>(room, 480);
+}
+
+// validate_scene's checks and derivations on the device, from the bound buffers where they lie (ptk_derive.hip).
+// Returns PTK_OK when the scene passed and its structures are in place, 1 when a check failed or the scene is one
+// the device pass leaves to the host (whose walk over the shadow copies then names the fault), negative on a HIP error.
+// Blocks are numbered in breadth-first order here (the host numbers the top so and the rest depth first); the socket
+// table, stack need and maps are the same.
+static int derive_on_device(ptk_ctx* ctx, Object* nodes, Object* ids, Object* sph, Object* pln, Object* tri, int n_xf, int n_mats) {
+    const int n_nodes = (int)(nodes->nbytes / 32), n_ids = (int)(ids->nbytes / 4);
+    const int n_sph = (int)(sph->nbytes / 32), n_pln = (int)(pln->nbytes / 32), n_tri = (int)(tri->nbytes / 80);
+    if (n_nodes > 0x00FFFFFF) return 1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_info = take(256), o_ent_node = take((size_t)n_nodes * 4), o_ent_aux = take((size_t)n_nodes * 4);
+    const size_t o_vis = take(((size_t)n_nodes + 31) / 32 * 4);
+    const size_t o_blk = take((size_t)n_nodes * 4), o_sock = take((size_t)n_nodes * 4), o_slot = take((size_t)n_nodes * 4);
+    const size_t o_tri = take((size_t)std::max(n_tri, 1) * 4), o_sph = take((size_t)std::max(n_sph, 1) * 4);
+    const size_t o_mat = take((size_t)std::max(n_mats, 1));
+    const size_t o_part = take((((size_t)n_nodes + 1023) / 1024 + 1) * 8);
+    if (off > ctx->derive_bytes) {
+        if (ctx->d_derive) { (void)hipFree(ctx->d_derive); ctx->d_derive = nullptr; }
+        ctx->derive_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_derive, off + off / 4));
+        ctx->derive_bytes = off + off / 4;
+    }
+    uint8_t* const base = (uint8_t*)ctx->d_derive;
+    PtkDerive D;
+    memset(&D, 0, sizeof D);
+    D.nodes = (const int32_t*)nodes->dev; D.ids = (const int32_t*)ids->dev;
+    D.spheres = (const float4*)sph->dev; D.planes = (const float4*)pln->dev; D.triangles = (const float4*)tri->dev;
+    D.n_nodes = n_nodes; D.n_ids = n_ids; D.n_sph = n_sph; D.n_pln = n_pln; D.n_tri = n_tri; D.n_xf = n_xf; D.n_mats = n_mats;
+    D.info = (PtkDeriveInfo*)(base + o_info);
+    D.ent_node = (uint32_t*)(base + o_ent_node); D.ent_aux = (uint32_t*)(base + o_ent_aux);
+    D.visited = (uint32_t*)(base + o_vis);
+    D.node_blk = (int32_t*)(base + o_blk); D.node_sock = (int32_t*)(base + o_sock); D.node_slot = (int32_t*)(base + o_slot);
+    D.tri_slot = (int32_t*)(base + o_tri); D.sph_slot = (int32_t*)(base + o_sph);
+    D.mat_used = base + o_mat;
+    D.partial = (uint2*)(base + o_part);
+    HIP_TRY(ctx, hipMemsetAsync(base + o_vis, 0, o_blk - o_vis, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(base + o_blk, 0xFF, o_mat - o_blk, ctx->stream));  // node_blk .. sph_slot: -1
+    HIP_TRY(ctx, hipMemsetAsync(base + o_mat, 0, o_part - o_mat, ctx->stream));
+    HIP_TRY(ctx, ptk_launch_derive_begin(&D, ctx->stream));
+    PtkDeriveInfo info;
+    memset(&info, 0, sizeof info);
+    // the tree's depth is not known beforehand: levels go out in batches; a finished list turns the rest of a batch into no-ops
+    for (int batch = 0; !info.finished; batch++) {
+        if (batch > 40) return 1;
+        HIP_TRY(ctx, ptk_launch_derive_levels(&D, 16, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&info, D.info, sizeof info, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (info.error) return 1;
+    const int stack_need = std::max(1, (int)info.stack_max + 1);
+    if (stack_need > 1024) return 1;
+    const uint32_t n_reached = info.end;
+    bool wf_ok = info.nested_socket == 0 && info.n_blocks <= 0x00FFFFFFu;
+    const uint32_t n_blocks = wf_ok ? info.n_blocks : 0u, n_sockets = wf_ok ? info.n_sockets : 0u;
+    { int r = reserve_blocks(ctx, n_blocks, n_sockets); if (r != PTK_OK) return r; }
+    // the first rows of both tables are all derive_chain reads: the chain's steps are the tree's first levels
+    const uint32_t head_blocks = std::min<uint32_t>(n_blocks, PTK_MAX_CHAIN + 2), head_sockets = std::min<uint32_t>(n_sockets, PTK_MAX_CHAIN + 2);
+    ctx->h_blocks.assign((size_t)head_blocks * 64, 0.0f);
+    ctx->h_sockets.assign((size_t)head_sockets * 2, 0);
+    ctx->mat_used.assign((size_t)n_mats, 0);
+    if (wf_ok) {
+        HIP_TRY(ctx, ptk_launch_derive_number(&D, n_reached, ctx->stream));
+        HIP_TRY(ctx, ptk_launch_derive_fill(&D, n_reached, (float*)ctx->d_blocks, (int32_t*)ctx->d_sockets, ctx->stream));
+        if (head_blocks) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_blocks.data(), ctx->d_blocks, (size_t)head_blocks * 256, hipMemcpyDeviceToHost, ctx->stream));
+        if (head_sockets) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_sockets.data(), ctx->d_sockets, (size_t)head_sockets * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (n_mats) HIP_TRY(ctx, hipMemcpyAsync(ctx->mat_used.data(), D.mat_used, (size_t)n_mats, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stack_need = stack_need;
+    ctx->wf_ok = wf_ok;
+    ctx->n_top = (uint32_t)std::min<size_t>(n_blocks, top_block_limit(ctx, stack_need));
+    ctx->n_blocks = n_blocks;
+    ctx->n_sockets = n_sockets;
+    ctx->leaves_hold_triangles = info.has_tri != 0;
+    // the root is the first node of the breadth-first order: block 0, or socket 0
+    {
+        int32_t id, x;
+        memcpy(&id, nodes->shadow.data() + 12, 4);
+        memcpy(&x, nodes->shadow.data() + 28, 4);
+        const int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
+        ctx->tree_entry = idx <= 0 ? (uint32_t)id : x >= 0 ? 0x7F000000u : ((uint32_t)size << 24);
+        memcpy(ctx->root_box, nodes->shadow.data(), 12);
+        memcpy(ctx->root_box + 3, nodes->shadow.data() + 16, 12);
+    }
+    ctx->node_slot.clear(); ctx->tri_slot.clear(); ctx->sph_slot.clear();
+    ctx->d_node_slot = D.node_slot; ctx->d_tri_slot = D.tri_slot; ctx->d_sph_slot = D.sph_slot;
+    ctx->mirrors_partial = true;
+    ctx->derive_levels = (int)info.level;
+    ctx->device_derivations++;
+    return PTK_OK;
+}
+
 // Walks the node buffer exactly as the kernel will and checks every index it
 // can reach, and computes the deepest the traversal stack can get.
 static int validate_scene(ptk_ctx* ctx) {
+    const auto t_begin = std::chrono::steady_clock::now();
     Object* nodes = bound_buffer(ctx, PTK_SET_BVH, 0);
     Object* ids = bound_buffer(ctx, PTK_SET_BVH, 1);
     Object* mats = bound_buffer(ctx, PTK_SET_OBJECT, 0);
@@ -998,158 +1160,170 @@ static int validate_scene(ptk_ctx* ctx) {
     const int n_xf = (int)(xf->nbytes / 64);
     if (n_mats < 1) return fail(ctx, PTK_E_INVALID, "material buffer holds no record");
 
-    auto mat_ok = [&](int m) { return m >= 0 && m < n_mats; };
-    // material indices of every primitive the kernel may resolve
-    for (int i = 0; i < n_sph; i++) { int32_t m; memcpy(&m, sph->shadow.data() + (size_t)i * 32 + 16, 4); if (!mat_ok(m)) return fail(ctx, PTK_E_INVALID, "sphere %d: material index %d out of range", i, m); }
-    for (int i = 0; i < n_pln; i++) { int32_t m; memcpy(&m, pln->shadow.data() + (size_t)i * 32 + 16, 4); if (!mat_ok(m)) return fail(ctx, PTK_E_INVALID, "plane %d: material index %d out of range", i, m); }
-    for (int i = 0; i < n_tri; i++) { int32_t m; memcpy(&m, tri->shadow.data() + (size_t)i * 80 + 64, 4); if (!mat_ok(m)) return fail(ctx, PTK_E_INVALID, "triangle %d: material index %d out of range", i, m); }
-
-    NodeView nv{nodes->shadow.data(), n_nodes};
+    // large trees are checked and compiled on the device, small ones by the walk below (a handful of launches and two
+    // round trips cost more than walking a few thousand nodes); a scene the device pass refuses is walked here too,
+    // which is what names the fault
+    bool on_device = false;
+    if (ctx->device_derive == 1 || (ctx->device_derive < 0 && n_nodes >= 4096)) {
+        const int r = derive_on_device(ctx, nodes, ids, sph, pln, tri, n_xf, n_mats);
+        if (r < 0) return r;
+        on_device = r == PTK_OK;
+    }
     const int32_t* idp = (const int32_t*)ids->shadow.data();
-    // depth-first walk; need(node) = how far the stack can grow above its level
-    // while the subtree of a popped node is processed: all k children are pushed
-    // at once, then each is popped with up to k-1 siblings still below it.
-    std::vector<uint8_t> visited((size_t)n_nodes, 0);
-    bool wf_ok = true;
-    std::string walk_error;
-    int walk_code = PTK_OK;
-    struct Walker {
-        const NodeView& nv; const int32_t* idp; std::vector<uint8_t>& visited;
-        int n_nodes, n_ids, n_sph, n_tri, n_xf;
-        std::string& err; int& code;
-        bool bad(int c, const char* fmt, int a = 0, int b = 0, int d = 0) {
-            char buf[256]; snprintf(buf, sizeof buf, fmt, a, b, d); err = buf; code = c; return false;
-        }
-        bool& wf_ok;
-        bool need(int i, int depth, bool in_mesh, int& out) {
-            if (i < 0 || i >= n_nodes) return bad(PTK_E_INVALID, "BVH references node %d outside the buffer (%d nodes)", i, n_nodes);
-            if (visited[i]) return bad(PTK_E_INVALID, "BVH node %d is reachable twice (not a tree)", i);
-            visited[i] = 1;
-            if (depth > 512) return bad(PTK_E_UNSUPPORTED, "BVH deeper than 512 levels");
-            int id = nv.node_id(i);
-            int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
-            int x = nv.xform(i);
-            // The kernels tell a leaf from an inner node by the sign of the whole word.  That equals the
-            // shader's test on the 24-bit index (ray_tracer.comp:1137) for every id PTBVHTree writes
-            // (pt_bvh_tree.gd:910-959: inner = index ^ count << 24 with both positive, leaf = negative
-            // index ^ (count - 1) << 24); any other bit pattern is refused rather than misread.
-            if ((idx > 0 && id <= 0) || (idx < 0 && id >= 0))
-                return bad(PTK_E_UNSUPPORTED, "node %d: id 0x%08x is not in the encoding PTBVHTree writes", i, id);
-            if (x >= n_xf) return bad(PTK_E_INVALID, "node %d: transform index %d out of range (%d)", i, x, n_xf);
-            // (an all-zero root, the empty tree, has transform index 0 and child index 0: harmless)
-            if (x >= 0 && idx < 0) return bad(PTK_E_INVALID, "node %d: a mesh socket (transform index %d) must have a child node", i, x);
-            if (x >= 0 && in_mesh) wf_ok = false;  // a mesh socket below another: one-kernel renderer only
-            const bool child_in_mesh = in_mesh || x >= 0;
-            if (idx <= 0) {
-                int base = std::abs(idx) - 1;
-                if (size > 0 && (base < 0 || base + size > n_ids)) return bad(PTK_E_INVALID, "leaf %d: object id slots from %d (count %d) outside the id buffer", i, base, size);
-                for (int k = 0; k < size; k++) {
-                    int oid = idp[base + k];
-                    int type = sext(oid, 24, 8), oi = sext(oid, 0, 24);
-                    if (type == 1 && (oi < 0 || oi >= n_sph)) return bad(PTK_E_INVALID, "leaf %d: sphere index %d out of range", i, oi);
-                    if (type == 3 && (oi < 0 || oi >= n_tri)) return bad(PTK_E_INVALID, "leaf %d: triangle index %d out of range", i, oi);
+    if (!on_device) {
+        ctx->mirrors_partial = false;
+        ctx->derive_levels = 0;
+        auto mat_ok = [&](int m) { return m >= 0 && m < n_mats; };
+        // material indices of every primitive the kernel may resolve
+        for (int i = 0; i < n_sph; i++) { int32_t m; memcpy(&m, sph->shadow.data() + (size_t)i * 32 + 16, 4); if (!mat_ok(m)) return fail(ctx, PTK_E_INVALID, "sphere %d: material index %d out of range", i, m); }
+        for (int i = 0; i < n_pln; i++) { int32_t m; memcpy(&m, pln->shadow.data() + (size_t)i * 32 + 16, 4); if (!mat_ok(m)) return fail(ctx, PTK_E_INVALID, "plane %d: material index %d out of range", i, m); }
+        for (int i = 0; i < n_tri; i++) { int32_t m; memcpy(&m, tri->shadow.data() + (size_t)i * 80 + 64, 4); if (!mat_ok(m)) return fail(ctx, PTK_E_INVALID, "triangle %d: material index %d out of range", i, m); }
+
+        NodeView nv{nodes->shadow.data(), n_nodes};
+        // depth-first walk; need(node) = how far the stack can grow above its level
+        // while the subtree of a popped node is processed: all k children are pushed
+        // at once, then each is popped with up to k-1 siblings still below it.
+        std::vector<uint8_t> visited((size_t)n_nodes, 0);
+        bool wf_ok = true;
+        std::string walk_error;
+        int walk_code = PTK_OK;
+        struct Walker {
+            const NodeView& nv; const int32_t* idp; std::vector<uint8_t>& visited;
+            int n_nodes, n_ids, n_sph, n_tri, n_xf;
+            std::string& err; int& code;
+            bool bad(int c, const char* fmt, int a = 0, int b = 0, int d = 0) {
+                char buf[256]; snprintf(buf, sizeof buf, fmt, a, b, d); err = buf; code = c; return false;
+            }
+            bool& wf_ok;
+            bool need(int i, int depth, bool in_mesh, int& out) {
+                if (i < 0 || i >= n_nodes) return bad(PTK_E_INVALID, "BVH references node %d outside the buffer (%d nodes)", i, n_nodes);
+                if (visited[i]) return bad(PTK_E_INVALID, "BVH node %d is reachable twice (not a tree)", i);
+                visited[i] = 1;
+                if (depth > 512) return bad(PTK_E_UNSUPPORTED, "BVH deeper than 512 levels");
+                int id = nv.node_id(i);
+                int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
+                int x = nv.xform(i);
+                // The kernels tell a leaf from an inner node by the sign of the whole word.  That equals the
+                // shader's test on the 24-bit index (ray_tracer.comp:1137) for every id PTBVHTree writes
+                // (pt_bvh_tree.gd:910-959: inner = index ^ count << 24 with both positive, leaf = negative
+                // index ^ (count - 1) << 24); any other bit pattern is refused rather than misread.
+                if ((idx > 0 && id <= 0) || (idx < 0 && id >= 0))
+                    return bad(PTK_E_UNSUPPORTED, "node %d: id 0x%08x is not in the encoding PTBVHTree writes", i, id);
+                if (x >= n_xf) return bad(PTK_E_INVALID, "node %d: transform index %d out of range (%d)", i, x, n_xf);
+                // (an all-zero root, the empty tree, has transform index 0 and child index 0: harmless)
+                if (x >= 0 && idx < 0) return bad(PTK_E_INVALID, "node %d: a mesh socket (transform index %d) must have a child node", i, x);
+                if (x >= 0 && in_mesh) wf_ok = false;  // a mesh socket below another: one-kernel renderer only
+                const bool child_in_mesh = in_mesh || x >= 0;
+                if (idx <= 0) {
+                    int base = std::abs(idx) - 1;
+                    if (size > 0 && (base < 0 || base + size > n_ids)) return bad(PTK_E_INVALID, "leaf %d: object id slots from %d (count %d) outside the id buffer", i, base, size);
+                    for (int k = 0; k < size; k++) {
+                        int oid = idp[base + k];
+                        int type = sext(oid, 24, 8), oi = sext(oid, 0, 24);
+                        if (type == 1 && (oi < 0 || oi >= n_sph)) return bad(PTK_E_INVALID, "leaf %d: sphere index %d out of range", i, oi);
+                        if (type == 3 && (oi < 0 || oi >= n_tri)) return bad(PTK_E_INVALID, "leaf %d: triangle index %d out of range", i, oi);
+                    }
+                    out = 0;
+                    return true;
                 }
-                out = 0;
+                if (size > PTK_MAX_WIDTH) return bad(PTK_E_UNSUPPORTED, "node %d has %d children; the kernels handle at most %d", i, size, PTK_MAX_WIDTH);
+                if (idx + size > n_nodes) return bad(PTK_E_INVALID, "node %d: children from %d (count %d) outside the buffer", i, idx, size);
+                int best = size;
+                for (int l = 0; l < size; l++) {
+                    int c = 0;
+                    if (!need(idx + l, depth + 1, child_in_mesh, c)) return false;
+                    best = std::max(best, size - 1 + c);
+                }
+                out = best;
                 return true;
             }
-            if (size > PTK_MAX_WIDTH) return bad(PTK_E_UNSUPPORTED, "node %d has %d children; the kernels handle at most %d", i, size, PTK_MAX_WIDTH);
-            if (idx + size > n_nodes) return bad(PTK_E_INVALID, "node %d: children from %d (count %d) outside the buffer", i, idx, size);
-            int best = size;
-            for (int l = 0; l < size; l++) {
-                int c = 0;
-                if (!need(idx + l, depth + 1, child_in_mesh, c)) return false;
-                best = std::max(best, size - 1 + c);
-            }
-            out = best;
-            return true;
-        }
-    } walker{nv, idp, visited, n_nodes, n_ids, n_sph, n_tri, n_xf, walk_error, walk_code, wf_ok};
-    int result = 0;
-    if (!walker.need(0, 0, false, result)) return fail(ctx, walk_code, "%s", walk_error.c_str());
-    ctx->stack_need = std::max(1, result + 1);
-    if (ctx->stack_need > 1024)
-        return fail(ctx, PTK_E_UNSUPPORTED, "BVH can need %d stack entries; the reference's traversal stack holds 1024", ctx->stack_need);
-    if (n_nodes > 0x00FFFFFF) wf_ok = false;
-    ctx->wf_ok = wf_ok;
+        } walker{nv, idp, visited, n_nodes, n_ids, n_sph, n_tri, n_xf, walk_error, walk_code, wf_ok};
+        int result = 0;
+        if (!walker.need(0, 0, false, result)) return fail(ctx, walk_code, "%s", walk_error.c_str());
+        ctx->stack_need = std::max(1, result + 1);
+        if (ctx->stack_need > 1024)
+            return fail(ctx, PTK_E_UNSUPPORTED, "BVH can need %d stack entries; the reference's traversal stack holds 1024", ctx->stack_need);
+        if (n_nodes > 0x00FFFFFF) wf_ok = false;
+        ctx->wf_ok = wf_ok;
 
-    // Compile the inner nodes for the traversal kernel (layout in PtkWavefront): block b holds the boxes
-    // and entries of one inner node's children; blocks are numbered parent first, depth first.
-    std::vector<float>& blocks = ctx->h_blocks;
-    blocks.clear();
-    std::vector<int32_t>& sockets = ctx->h_sockets;
-    sockets.clear();
-    ctx->node_slot.assign((size_t)n_nodes, -1);
-    ctx->n_top = 0;
-    if (wf_ok) {
-        // Block numbers: the top of the tree first, breadth-first from the root (through world-level mesh
-        // sockets into the meshes), as many blocks as the traversal kernel's LDS has room for beside its
-        // stack windows; everything below in depth-first order, parent first.
-        std::vector<int32_t> block_of((size_t)n_nodes, -1);
-        uint32_t next_free = 0;
-        {
-            const size_t stacks = (size_t)PTK_WF_WG_WAVES * (std::min(ctx->stack_need, ctx->lds_window) + 1) * 256 + PTK_WF_WG_FLAG_BYTES;
-            const size_t room = PTK_LDS_BYTES_PER_CU > stacks ? (PTK_LDS_BYTES_PER_CU - stacks) / PTK_TOP_BLOCK_STRIDE : 0;
-            const size_t limit = std::min<size_t>(room, 480);
-            std::vector<std::pair<int, bool>> queue = {{0, false}};  // node, inside a mesh
-            for (size_t q = 0; q < queue.size() && next_free < limit; q++) {
-                const int i = queue[q].first;
-                const bool in_mesh = queue[q].second;
-                const int id = nv.node_id(i);
-                const int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
-                if (idx <= 0) continue;  // leaf
-                if (nv.xform(i) >= 0 && !in_mesh) { queue.push_back({idx, true}); continue; }  // socket: its child is the mesh's root
-                block_of[i] = (int32_t)next_free++;
-                for (int l = 0; l < size; l++) queue.push_back({idx + l, in_mesh});
+        // Compile the inner nodes for the traversal kernel (layout in PtkWavefront): block b holds the boxes
+        // and entries of one inner node's children; blocks are numbered parent first, depth first.
+        std::vector<float>& blocks = ctx->h_blocks;
+        blocks.clear();
+        std::vector<int32_t>& sockets = ctx->h_sockets;
+        sockets.clear();
+        ctx->node_slot.assign((size_t)n_nodes, -1);
+        ctx->n_top = 0;
+        if (wf_ok) {
+            // Block numbers: the top of the tree first, breadth-first from the root (through world-level mesh
+            // sockets into the meshes), as many blocks as the traversal kernel's LDS has room for beside its
+            // stack windows; everything below in depth-first order, parent first.
+            std::vector<int32_t> block_of((size_t)n_nodes, -1);
+            uint32_t next_free = 0;
+            {
+                const size_t stacks = (size_t)PTK_WF_WG_WAVES * (std::min(ctx->stack_need, ctx->lds_window) + 1) * 256 + PTK_WF_WG_FLAG_BYTES;
+                const size_t room = PTK_LDS_BYTES_PER_CU > stacks ? (PTK_LDS_BYTES_PER_CU - stacks) / PTK_TOP_BLOCK_STRIDE : 0;
+                const size_t limit = std::min<size_t>(room, 480);
+                std::vector<std::pair<int, bool>> queue = {{0, false}};  // node, inside a mesh
+                for (size_t q = 0; q < queue.size() && next_free < limit; q++) {
+                    const int i = queue[q].first;
+                    const bool in_mesh = queue[q].second;
+                    const int id = nv.node_id(i);
+                    const int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
+                    if (idx <= 0) continue;  // leaf
+                    if (nv.xform(i) >= 0 && !in_mesh) { queue.push_back({idx, true}); continue; }  // socket: its child is the mesh's root
+                    block_of[i] = (int32_t)next_free++;
+                    for (int l = 0; l < size; l++) queue.push_back({idx + l, in_mesh});
+                }
+                ctx->n_top = next_free;
             }
-            ctx->n_top = next_free;
+            struct Compiler {
+                const NodeView& nv; std::vector<float>& blocks; std::vector<int32_t>& sockets; std::vector<int32_t>& node_slot;
+                const std::vector<int32_t>& block_of; uint32_t& next_free;
+                uint32_t compile(int i, bool in_mesh, int depth = 0) {
+                    const int id = nv.node_id(i);
+                    const int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
+                    const int x = nv.xform(i);
+                    if (idx <= 0) return (uint32_t)id;  // leaf
+                    if (x >= 0 && !in_mesh) {           // world-level socket: its child is the mesh's root
+                        const uint32_t child = compile(idx, true, depth);
+                        const int sidx = (int)(sockets.size() / 2);
+                        sockets.push_back((int32_t)child);
+                        sockets.push_back(x);
+                        return 0x7F000000u | (uint32_t)sidx;
+                    }
+                    const size_t b = block_of[i] >= 0 ? (size_t)block_of[i] : (size_t)next_free++;
+                    if (blocks.size() < (b + 1) * 64) blocks.resize((b + 1) * 64, 0.0f);
+                    memcpy(blocks.data() + b * 64 + 56, &depth, 4);  // first spare word: the block's depth (measurement builds read it)
+                    for (int l = 0; l < size; l++) {
+                        float box[8];
+                        memcpy(box, nv.p + (size_t)(idx + l) * 32, 32);
+                        const uint32_t e = compile(idx + l, in_mesh || x >= 0, depth + 1);
+                        float* blk = blocks.data() + b * 64;  // (re-read: compile() may have grown the vector)
+                        blk[0 + l] = box[0]; blk[8 + l] = box[1]; blk[16 + l] = box[2];
+                        blk[24 + l] = box[4]; blk[32 + l] = box[5]; blk[40 + l] = box[6];
+                        memcpy(blk + 48 + l, &e, 4);
+                        node_slot[(size_t)idx + l] = (int32_t)(b * 8 + l);
+                    }
+                    return (uint32_t)b | ((uint32_t)size << 24);
+                }
+            } compiler{nv, blocks, sockets, ctx->node_slot, block_of, next_free};
+            blocks.resize((size_t)next_free * 64, 0.0f);
+            ctx->tree_entry = compiler.compile(0, false);
+            memcpy(ctx->root_box, nv.p, 12);
+            memcpy(ctx->root_box + 3, nv.p + 16, 12);
+            if (blocks.size() / 64 > 0x00FFFFFF) ctx->wf_ok = false;
         }
-        struct Compiler {
-            const NodeView& nv; std::vector<float>& blocks; std::vector<int32_t>& sockets; std::vector<int32_t>& node_slot;
-            const std::vector<int32_t>& block_of; uint32_t& next_free;
-            uint32_t compile(int i, bool in_mesh, int depth = 0) {
-                const int id = nv.node_id(i);
-                const int idx = sext(id, 0, 24), size = std::abs(sext(id, 24, 8));
-                const int x = nv.xform(i);
-                if (idx <= 0) return (uint32_t)id;  // leaf
-                if (x >= 0 && !in_mesh) {           // world-level socket: its child is the mesh's root
-                    const uint32_t child = compile(idx, true, depth);
-                    const int sidx = (int)(sockets.size() / 2);
-                    sockets.push_back((int32_t)child);
-                    sockets.push_back(x);
-                    return 0x7F000000u | (uint32_t)sidx;
-                }
-                const size_t b = block_of[i] >= 0 ? (size_t)block_of[i] : (size_t)next_free++;
-                if (blocks.size() < (b + 1) * 64) blocks.resize((b + 1) * 64, 0.0f);
-                memcpy(blocks.data() + b * 64 + 56, &depth, 4);  // first spare word: the block's depth (measurement builds read it)
-                for (int l = 0; l < size; l++) {
-                    float box[8];
-                    memcpy(box, nv.p + (size_t)(idx + l) * 32, 32);
-                    const uint32_t e = compile(idx + l, in_mesh || x >= 0, depth + 1);
-                    float* blk = blocks.data() + b * 64;  // (re-read: compile() may have grown the vector)
-                    blk[0 + l] = box[0]; blk[8 + l] = box[1]; blk[16 + l] = box[2];
-                    blk[24 + l] = box[4]; blk[32 + l] = box[5]; blk[40 + l] = box[6];
-                    memcpy(blk + 48 + l, &e, 4);
-                    node_slot[(size_t)idx + l] = (int32_t)(b * 8 + l);
-                }
-                return (uint32_t)b | ((uint32_t)size << 24);
-            }
-        } compiler{nv, blocks, sockets, ctx->node_slot, block_of, next_free};
-        blocks.resize((size_t)next_free * 64, 0.0f);
-        ctx->tree_entry = compiler.compile(0, false);
-        memcpy(ctx->root_box, nv.p, 12);
-        memcpy(ctx->root_box + 3, nv.p + 16, 12);
-        if (blocks.size() / 64 > 0x00FFFFFF) ctx->wf_ok = false;
+        ctx->n_blocks = (uint32_t)(blocks.size() / 64);
+        ctx->n_sockets = (uint32_t)(sockets.size() / 2);
+        ctx->n_records = (uint32_t)std::max(n_ids, 0);
+        { int r = reserve_blocks(ctx, blocks.size() / 64, sockets.size() / 2); if (r != PTK_OK) return r; }
+        if (!blocks.empty()) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blocks, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (!sockets.empty()) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sockets, sockets.data(), sockets.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+
     }
     derive_chain(ctx);
-    ctx->n_blocks = (uint32_t)(blocks.size() / 64);
-    ctx->n_sockets = (uint32_t)(sockets.size() / 2);
     ctx->n_records = (uint32_t)std::max(n_ids, 0);
-    if (ctx->d_blocks) { (void)hipFree(ctx->d_blocks); ctx->d_blocks = nullptr; }
-    if (ctx->d_sockets) { (void)hipFree(ctx->d_sockets); ctx->d_sockets = nullptr; }
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_blocks, std::max<size_t>(256, blocks.size() * 4)));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sockets, std::max<size_t>(8, sockets.size() * 4)));
-    if (!blocks.empty()) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blocks, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (!sockets.empty()) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sockets, sockets.data(), sockets.size() * 4, hipMemcpyHostToDevice, ctx->stream));
 
     // leaf records: what a leaf tests for object-id slot i, by value, so the traversal kernel reads a
     // leaf's primitives from consecutive addresses without going through the id table first.  They are made on
@@ -1160,29 +1334,31 @@ static int validate_scene(ptk_ctx* ctx) {
         ctx->h_leaf_records.reset(new float[n_slots * 12]);
         ctx->h_leaf_records_slots = n_slots;
     }
-    ctx->tri_slot.assign((size_t)n_tri, -1);
-    ctx->sph_slot.assign((size_t)n_sph, -1);
-    ctx->leaves_hold_triangles = false;
-    ctx->mat_used.assign((size_t)n_mats, 0);
-    for (int i = 0; i < n_ids; i++) {
-        const int oid = idp[i];
-        const int type = sext(oid, 24, 8), oi = sext(oid, 0, 24);
-        if (type == 3 && oi >= 0 && oi < n_tri) {
-            ctx->leaves_hold_triangles = true;
-            ctx->tri_slot[oi] = ctx->tri_slot[oi] == -1 ? i : -2;  // -2: listed more than once
-            int32_t m; memcpy(&m, tri->shadow.data() + (size_t)oi * 80 + 64, 4);
-            ctx->mat_used[m] = 1;  // (in range: checked for every record above)
-        } else if (type == 1 && oi >= 0 && oi < n_sph) {
-            ctx->sph_slot[oi] = ctx->sph_slot[oi] == -1 ? i : -2;
-            int32_t m; memcpy(&m, sph->shadow.data() + (size_t)oi * 32 + 16, 4);
-            ctx->mat_used[m] = 1;
+    if (!on_device) {  // (the device pass has made these maps, and keeps them until an edit needs them here)
+        ctx->tri_slot.assign((size_t)n_tri, -1);
+        ctx->sph_slot.assign((size_t)n_sph, -1);
+        ctx->leaves_hold_triangles = false;
+        ctx->mat_used.assign((size_t)n_mats, 0);
+        for (int i = 0; i < n_ids; i++) {
+            const int oid = idp[i];
+            const int type = sext(oid, 24, 8), oi = sext(oid, 0, 24);
+            if (type == 3 && oi >= 0 && oi < n_tri) {
+                ctx->leaves_hold_triangles = true;
+                ctx->tri_slot[oi] = ctx->tri_slot[oi] == -1 ? i : -2;  // -2: listed more than once
+                int32_t m; memcpy(&m, tri->shadow.data() + (size_t)oi * 80 + 64, 4);
+                ctx->mat_used[m] = 1;  // (in range: checked for every record above)
+            } else if (type == 1 && oi >= 0 && oi < n_sph) {
+                ctx->sph_slot[oi] = ctx->sph_slot[oi] == -1 ? i : -2;
+                int32_t m; memcpy(&m, sph->shadow.data() + (size_t)oi * 32 + 16, 4);
+                ctx->mat_used[m] = 1;
+            }
         }
-    }
-    for (int i = 0; i < n_pln; i++) {  // planes are tested outside the tree: every record that can be hit
-        float nrm[3]; int32_t m;
-        memcpy(nrm, pln->shadow.data() + (size_t)i * 32, 12);
-        memcpy(&m, pln->shadow.data() + (size_t)i * 32 + 16, 4);
-        if (!(nrm[0] == 0.0f && nrm[1] == 0.0f && nrm[2] == 0.0f)) ctx->mat_used[m] = 1;
+        for (int i = 0; i < n_pln; i++) {  // planes are tested outside the tree: every record that can be hit
+            float nrm[3]; int32_t m;
+            memcpy(nrm, pln->shadow.data() + (size_t)i * 32, 12);
+            memcpy(&m, pln->shadow.data() + (size_t)i * 32 + 16, 4);
+            if (!(nrm[0] == 0.0f && nrm[1] == 0.0f && nrm[2] == 0.0f)) ctx->mat_used[m] = 1;
+        }
     }
     refresh_may_refract(ctx);
     if (n_slots > ctx->d_leaf_records_slots) {
@@ -1197,7 +1373,7 @@ static int validate_scene(ptk_ctx* ctx) {
     // the derived structures were uploaded whole: nothing of them is pending any more
     ctx->dirty_blocks.clear();
     ctx->dirty_slots.clear();
-    ctx->block_is_dirty.assign(ctx->h_blocks.size() / 64 + 1, 0);
+    ctx->block_is_dirty.assign((size_t)ctx->n_blocks + 1, 0);
     ctx->slot_is_dirty.assign((size_t)std::max(n_ids, 1), 0);
     { int r = refresh_live_planes(ctx, pln); if (r != PTK_OK) return r; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1219,6 +1395,7 @@ static int validate_scene(ptk_ctx* ctx) {
     ctx->dirty = false;
     ctx->full_validations++;
     ctx->scene_version++;
+    ctx->last_validate_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return PTK_OK;
 }
 
@@ -1719,6 +1896,46 @@ int ptk_dev_wf_ends(ptk_ctx* ctx, unsigned long long* out, size_t n) {
     return PTK_OK;
 }
 #endif
+
+// Development aid (not declared in ptk.h): the structures derived from the bound scene, for tests that compare the
+// host's and the device's derivation.  kind 0: blocks (64 words each), 1: socket table (2 words a row), 2: node ->
+// child slot, 3: triangle -> id slot, 4: sphere -> id slot, 5: {stack need, top blocks, blocks, sockets, block
+// traversal covers the scene, levels the device pass walked (0: host), root entry, paths may refract, leaves hold
+// triangles, device derivations so far, host microseconds of the last validation}.  *n = words there are; at most `capacity` are copied.
+extern "C" int ptk_dev_read_derived(ptk_ctx* ctx, int kind, uint32_t* out, size_t capacity, size_t* n) {
+    if (!ctx || !n || ctx->dirty) return PTK_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    Object* nodes = bound_buffer(ctx, PTK_SET_BVH, 0);
+    Object* tri = bound_buffer(ctx, PTK_SET_OBJECT, 3);
+    Object* sph = bound_buffer(ctx, PTK_SET_OBJECT, 1);
+    if (!nodes || !tri || !sph) return PTK_E_STATE;
+    const void* dev = nullptr;
+    const void* host = nullptr;
+    size_t words = 0;
+    uint32_t info[11];
+    switch (kind) {
+    case 0: words = (size_t)ctx->n_blocks * 64; dev = ctx->d_blocks; break;
+    case 1: words = (size_t)ctx->n_sockets * 2; dev = ctx->d_sockets; break;
+    case 2: words = nodes->nbytes / 32; if (ctx->mirrors_partial) dev = ctx->d_node_slot; else host = ctx->node_slot.data(); break;
+    case 3: words = tri->nbytes / 80; if (ctx->mirrors_partial) dev = ctx->d_tri_slot; else host = ctx->tri_slot.data(); break;
+    case 4: words = sph->nbytes / 32; if (ctx->mirrors_partial) dev = ctx->d_sph_slot; else host = ctx->sph_slot.data(); break;
+    case 5:
+        info[0] = (uint32_t)ctx->stack_need; info[1] = ctx->n_top; info[2] = ctx->n_blocks; info[3] = ctx->n_sockets;
+        info[4] = ctx->wf_ok ? 1u : 0u; info[5] = (uint32_t)ctx->derive_levels; info[6] = ctx->tree_entry;
+        info[7] = ctx->may_refract ? 1u : 0u; info[8] = ctx->leaves_hold_triangles ? 1u : 0u; info[9] = (uint32_t)ctx->device_derivations;
+        info[10] = (uint32_t)(ctx->last_validate_ms * 1000.0);
+        words = 11; host = info; break;
+    default: return PTK_E_INVALID;
+    }
+    *n = words;
+    const size_t copy = std::min(words, capacity);
+    if (copy && out) {
+        if (dev) HIP_TRY(ctx, hipMemcpy(out, dev, copy * 4, hipMemcpyDeviceToHost));
+        else memcpy(out, host, copy * 4);
+    }
+    return PTK_OK;
+}
 
 // Development aid (not declared in ptk.h): the pipeline's queue counters after its last dispatch: 65 words of counts
 // (rays queued for launch i), 65 of heads (rays handed out), then n_resume (searches parked for launch i).

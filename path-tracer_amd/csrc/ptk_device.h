@@ -213,6 +213,42 @@ struct PtkScatterEntry {
     uint32_t nbytes;
 };
 extern "C" hipError_t ptk_launch_scatter(const void* d_stage, uint32_t n_entries, hipStream_t stream);
+// Validation and derivation of the traversal structures on the device (ptk_derive.hip).
+struct PtkDeriveInfo {
+    uint32_t error;          // a check failed (the host's walk over its copy of the same bytes names it)
+    uint32_t total;          // entries of the level list handed out so far
+    uint32_t begin, end;     // the level the next launch processes: entries [begin, end)
+    uint32_t level;          // its depth
+    uint32_t finished;       // the list is complete: end = nodes reached, level = levels of the tree
+    uint32_t done_blocks;    // workgroups of the running level launch that are through
+    uint32_t stack_max;      // max over inner nodes of (stack entries below it + its children)
+    uint32_t nested_socket;  // a mesh socket inside a mesh: block traversal does not cover the scene
+    uint32_t n_blocks, n_sockets;  // inner nodes that get a block; world-level mesh sockets
+    uint32_t has_tri;        // the id table names a triangle
+    uint32_t pad[4];
+};
+struct PtkDerive {
+    const int32_t* nodes;    // bound node buffer, 8 words per node
+    const int32_t* ids;      // bound id table
+    const float4* spheres; const float4* planes; const float4* triangles;
+    int n_nodes, n_ids, n_sph, n_pln, n_tri, n_xf, n_mats;
+    PtkDeriveInfo* info;
+    uint32_t* ent_node;      // [n_nodes] the tree level by level: node | inside a mesh << 31
+    uint32_t* ent_aux;       // [n_nodes] stack entries below the node | its level << 16
+    uint32_t* visited;       // [(n_nodes + 31) / 32] zeroed
+    int32_t* node_blk;       // [n_nodes] -1: the node's block
+    int32_t* node_sock;      // [n_nodes] -1: the node's row of the socket table
+    int32_t* node_slot;      // [n_nodes] -1: block * 8 + child slot that holds the node's box
+    int32_t* tri_slot;       // [n_tri] -1: the id slot that names the triangle (-2: several do)
+    int32_t* sph_slot;       // [n_sph] -1
+    uint8_t* mat_used;       // [n_mats] 0: a primitive that can be hit has this material
+    uint2* partial;          // [(n_nodes + 1023) / 1024 + 1] scan scratch
+};
+extern "C" hipError_t ptk_launch_derive_begin(const PtkDerive* d, hipStream_t stream);
+extern "C" hipError_t ptk_launch_derive_levels(const PtkDerive* d, int n_levels, hipStream_t stream);
+extern "C" hipError_t ptk_launch_derive_number(const PtkDerive* d, uint32_t n_reached, hipStream_t stream);
+extern "C" hipError_t ptk_launch_derive_fill(const PtkDerive* d, uint32_t n_reached, float* blocks, int32_t* sockets, hipStream_t stream);
+
 // Leaf records (48 bytes per object-id slot) from the bound id table, triangle and sphere buffers, all on the device.
 extern "C" hipError_t ptk_launch_leaf_records(const int32_t* ids, int n_ids, const void* triangles80, int n_tri, const void* spheres32, int n_sph,
                                               void* out48, hipStream_t stream);

@@ -1,12 +1,16 @@
 """Host time of the first dispatch after a scene is bound (it validates the scene and derives the traversal
-structures) beside a later one, on the bench scene (development aid)."""
+structures) beside a later one, and of the dispatch after a scene change in a context whose queues are allocated
+already (the node buffer is written again as a whole), on the bench scene (development aid)."""
+import ctypes as C
 import importlib, os, sys, time
+import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pta = importlib.import_module("path-tracer_amd")
 wd = pta.work_dispatcher
 scene = pta.scenes.atrium_scene(262144, seed=7) if len(sys.argv) < 2 else pta.scenes.load_fixture_scene(sys.argv[1], os.path.join(ROOT, "tests", "golden"))
 rd = pta.PtkRenderingDevice(0)
+rd.lib.ptk_dev_read_derived.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
 disp = wd.PTWorkDispatcher(rd)
 disp.set_scene(scene)
 disp.create_buffers(1920, 1080, order=8)
@@ -14,11 +18,33 @@ disp.load_shader()
 rd.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
 win = wd.PTRenderWindow(render_width=1920, render_height=1080, max_ray_depth=8, max_refraction_bounces=4)
 rd.sync()
-for k in range(3):
+
+
+def validate_info():
+    out, n = np.zeros(16, np.uint32), C.c_size_t(0)
+    assert rd.lib.ptk_dev_read_derived(rd.ctx, 5, out.ctypes.data, 16, C.byref(n)) == 0
+    return "validation %.3f ms on the %s (%d levels)" % (out[10] / 1000.0, "device" if out[5] else "host", out[5])
+
+
+def dispatch(k, label):
     win.frame = k
     t0 = time.perf_counter()
     disp.create_compute_list(win, scene.camera, wd.sample_time(k))
     t1 = time.perf_counter()
     rd.sync()
     t2 = time.perf_counter()
-    print("dispatch %d: call %.3f ms, until done %.3f ms" % (k, (t1 - t0) * 1e3, (t2 - t0) * 1e3))
+    print("%s: call %.3f ms, until done %.3f ms" % (label, (t1 - t0) * 1e3, (t2 - t0) * 1e3))
+
+
+dispatch(0, "first dispatch of the context (allocates its queues)")
+print("  " + validate_info())
+dispatch(1, "next dispatch")
+nodes = bytes(disp.packed.bvh)
+if nodes is not None:
+    t0 = time.perf_counter()
+    rd.buffer_update(disp.bvh_buffer, 0, len(nodes), nodes)  # the whole tree again: a scene change
+    t1 = time.perf_counter()
+    print("node buffer written again: %.3f ms" % ((t1 - t0) * 1e3))
+    dispatch(2, "dispatch after the scene change")
+    print("  " + validate_info())
+    dispatch(3, "next dispatch")
