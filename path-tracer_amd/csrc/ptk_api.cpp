@@ -2178,6 +2178,44 @@ int ptk_bvh_bind(ptk_ctx* ctx, uint64_t bvh, uint64_t* nodes_buffer, uint64_t* i
     return PTK_OK;
 }
 
+// The records a refit queues (node index + 32 bytes each: new boxes, ids and transform indices as they were) reach the
+// bound node buffer in one pass: shadow copy, pending range, and -- when the derived structures are current -- the box
+// planes of the node's slot in its parent's block, with one look at the top-of-tree chain at the end.  A record that
+// changes more than a box goes the general way (ptk_buffer_update).
+static int apply_refit_records(ptk_ctx* ctx, uint64_t nodes_handle, const std::vector<int32_t>& nodes, const std::vector<uint8_t>& bytes) {
+    Object* o = find(ctx, nodes_handle, Kind::Buffer);
+    if (!o) return fail(ctx, PTK_E_STATE, "the bound tree's node buffer is gone");
+    const bool patch = !ctx->dirty && ctx->wf_ok && bound_buffer(ctx, o->set, o->binding) == o && nodes.size() <= 65536;
+    if (patch && !nodes.empty()) { int r = ensure_mirrors(ctx); if (r != PTK_OK) return r; }
+    for (size_t k = 0; k < nodes.size(); k++) {
+        const size_t i = (size_t)nodes[k];
+        const uint8_t* rec = bytes.data() + k * 32;
+        if ((i + 1) * 32 > o->nbytes) return fail(ctx, PTK_E_INVALID, "refit record for node %zu outside the buffer", i);
+        uint8_t* sh = o->shadow.data() + i * 32;
+        if (!patch || memcmp(sh + 12, rec + 12, 4) != 0 || memcmp(sh + 28, rec + 28, 4) != 0 || i >= ctx->node_slot.size()) {
+            int r = ptk_buffer_update(ctx, nodes_handle, i * 32, rec, 32);
+            if (r != PTK_OK) return r;
+            continue;
+        }
+        memcpy(sh, rec, 32);
+        ctx->pending.push_back({nodes_handle, i * 32, (size_t)32});
+        ctx->patched_updates++;
+        float box[8];
+        memcpy(box, rec, 32);
+        if (i == 0) { memcpy(ctx->root_box, box, 12); memcpy(ctx->root_box + 3, box + 4, 12); }
+        const int32_t ns = ctx->node_slot[i];
+        if (ns < 0) continue;  // the root, a mesh's root, or a node the traversal cannot reach
+        const size_t blk = (size_t)(ns >> 3) * 64, l = (size_t)(ns & 7);
+        float* h = ctx->h_blocks.data() + blk;
+        const int plane_of[6] = {0, 1, 2, 4, 5, 6};
+        for (int q = 0; q < 6; q++) h[q * 8 + l] = box[plane_of[q]];
+        const uint32_t bi = (uint32_t)(ns >> 3);
+        if (!ctx->block_is_dirty[bi]) { ctx->block_is_dirty[bi] = 1; ctx->dirty_blocks.push_back(bi); }
+    }
+    if (patch) derive_chain(ctx);  // (a patched box may be one of the chain's)
+    return PTK_OK;
+}
+
 int ptk_bvh_refit(ptk_ctx* ctx, const ptk_refit_event* events, int n_events, int32_t* n_nodes_updated) {
     if (!ctx) return PTK_E_INVALID;
     if (n_nodes_updated) *n_nodes_updated = 0;
@@ -2214,9 +2252,7 @@ int ptk_bvh_refit(ptk_ctx* ctx, const ptk_refit_event* events, int n_events, int
     // the queued nodes reach the bound node buffer the way the plugin's own dirty-node uploads do
     // (pt_renderer.gd:771-788): shadow copy, patched blocks, one staged transfer at the next flush
     ctx->in_refit = true;
-    int rc = PTK_OK;
-    for (size_t k = 0; k < nodes.size() && rc == PTK_OK; k++)
-        rc = ptk_buffer_update(ctx, bt->nodes_handle, (size_t)nodes[k] * 32, bytes.data() + k * 32, 32);
+    int rc = apply_refit_records(ctx, bt->nodes_handle, nodes, bytes);
     ctx->in_refit = false;
     if (rc != PTK_OK) return rc;
     if (n_nodes_updated) *n_nodes_updated = (int32_t)nodes.size();

@@ -26,6 +26,10 @@ struct PtkRefitState {
     int32_t *d_first_child = nullptr, *d_n_children = nullptr, *d_kind = nullptr, *d_slot_first = nullptr, *d_slot_count = nullptr,
             *d_mesh_of_socket = nullptr, *d_node_id = nullptr, *d_xform = nullptr, *d_rec_off = nullptr, *d_rec_cnt = nullptr;
     float *d_raw_box = nullptr, *d_obj_box = nullptr /* per id slot */, *d_xf12 = nullptr /* per mesh slot */;
+    // scratch of refit(): one device block and one pinned host block, kept between calls and grown when a call needs
+    // more (a call then makes one upload, one download and one wait, and allocates nothing once they are large enough)
+    void* d_ws = nullptr; void* h_ws = nullptr;
+    size_t d_ws_bytes = 0, h_ws_bytes = 0;
     ~PtkRefitState();
     // Runs the edits in order with the reference's update_aabb semantics (pt_bvh_tree.gd:254-302,873-882).
     // Out: flat indices of the nodes the reference would queue for upload and their new 32-byte records.

@@ -24,6 +24,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <initializer_list>
 
@@ -1718,12 +1721,16 @@ DEV A6 box_as_of(const RefitArgs& R, int c, int j) {
     return a6_load(R.raw_box, c);
 }
 
+// Segments of this many records or more at an inner node are run by a workgroup of their own (k_refit_level_wide)
+constexpr int REFIT_WIDE = 8;
+
 __global__ void k_refit_level(RefitArgs R, int seg_begin, int n_segs) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_segs) return;
     const int first = R.seg_first[seg_begin + t], count = R.seg_count[seg_begin + t];
     const int node = R.rec_node[first];
     const int kind = R.kind[node];
+    if (count >= REFIT_WIDE && kind != N_SOCKET && kind != N_LEAF) return;  // k_refit_level_wide's
     A6 cur = a6_load(R.raw_box, node);
     for (int r = first; r < first + count; r++) {
         const int j = R.rec_j[r];
@@ -1752,6 +1759,66 @@ __global__ void k_refit_level(RefitArgs R, int seg_begin, int n_segs) {
         }
         R.rec_changed[r] = changed;
         a6_store(R.rec_box, r, cur);
+    }
+}
+
+// The records of one inner node with many edits on their way through it (near the root every edit of a batch passes),
+// one workgroup per node.  What k_refit_level does record by record splits into steps that do not wait for each other:
+// a record is live iff its edit's update_aabb call reached the node (the child's record says so); a live record's box
+// is the merge of the children's boxes as of that edit, whatever the node's earlier records were; and it counts as a
+// change iff it differs (is_equal_approx) from the box the live record before it left -- the node's own at the start.
+// Records that are not live repeat that box.  seg_list: the segments (indices into seg_first / seg_count) to run.
+__global__ __launch_bounds__(256) void k_refit_level_wide(RefitArgs R, const int* __restrict__ seg_list) {
+    __shared__ int s_wave[4];
+    __shared__ int s_carry;
+    const int seg = seg_list[blockIdx.x];
+    const int first = R.seg_first[seg], count = R.seg_count[seg];
+    const int node = R.rec_node[first];
+    const int cb = R.first_child[node], cn = R.n_children[node];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = -1;  // last live record so far
+    __syncthreads();
+    for (int r0 = first; r0 < first + count; r0 += 256) {
+        const int r = r0 + (int)threadIdx.x;
+        const bool in = r < first + count;
+        bool live = false;
+        if (in) {
+            const int child_rec = R.rec_child[r];
+            live = child_rec < 0 || R.rec_changed[child_rec] != 0;
+            if (live) {
+                const int j = R.rec_j[r];
+                A6 acc = a6_zero();
+                for (int k = 0; k < cn; k++) acc = merge_aabb(acc, box_as_of(R, cb + k, j));
+                a6_store(R.rec_box, r, acc);
+            }
+        }
+        // last live record at or before r: a running maximum over the workgroup
+        int la = live ? r : -1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(la, d, 64);
+            if (lane >= d && y > la) la = y;
+        }
+        if (lane == 63) s_wave[wave] = la;
+        __syncthreads();  // (also: every live box of the chunk is stored)
+        int before = s_carry;  // ... before this thread's wave
+        for (int w = 0; w < wave; w++) before = s_wave[w] > before ? s_wave[w] : before;
+        if (before > la) la = before;
+        // the live record before r
+        int prev = __shfl_up(la, 1, 64);
+        if (lane == 0) prev = before;
+        if (in) {
+            A6 was = prev >= 0 ? a6_load(R.rec_box, prev) : a6_load(R.raw_box, node);
+            if (live) {
+                R.rec_changed[r] = a6_equal_approx(a6_load(R.rec_box, r), was) ? 0 : 1;
+            } else {
+                R.rec_changed[r] = 0;
+                a6_store(R.rec_box, r, was);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = la;
+        __syncthreads();
     }
 }
 
@@ -1794,6 +1861,8 @@ PtkRefitState::~PtkRefitState() {
         if (p) (void)hipFree(p);
     for (float* p : {d_raw_box, d_obj_box, d_xf12})
         if (p) (void)hipFree(p);
+    if (d_ws) (void)hipFree(d_ws);
+    if (h_ws) (void)hipHostFree(h_ws);
 }
 
 bool PtkRefitState::refit(hipStream_t st, const std::vector<PtkRefitEvent>& events, std::vector<int32_t>& nodes_out,
@@ -1802,6 +1871,11 @@ bool PtkRefitState::refit(hipStream_t st, const std::vector<PtkRefitEvent>& even
     bytes_out.clear();
     const int n_ev = (int)events.size();
     if (n_ev == 0) return true;
+    const bool timing = getenv("PTK_REFIT_TIMING") != nullptr;  // (development aid: where a call's host time goes, on stderr)
+    const auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (timing) fprintf(stderr, "refit %-10s %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
     // records: one per (edit, node on its path), grouped by node, deepest level first, edits in order inside a node
     struct Rec { int depth, node, j, idx_on_path; };
     std::vector<Rec> recs;
@@ -1812,6 +1886,7 @@ bool PtkRefitState::refit(hipStream_t st, const std::vector<PtkRefitEvent>& even
         for (int k = 0; node >= 0; node = parent[node], k++) recs.push_back({depth[node], node, j, k});
     }
     std::stable_sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.depth != b.depth ? a.depth > b.depth : a.node < b.node; });
+    lap("sorted");
     const int R = (int)recs.size();
     std::vector<int> rec_node(R), rec_j(R), rec_child(R, -1), seg_first, seg_count, level_first_seg, level_n_segs;
     // the record of edit j at the child on its path: the one record of that edit one step lower on the path
@@ -1835,48 +1910,91 @@ bool PtkRefitState::refit(hipStream_t st, const std::vector<PtkRefitEvent>& even
         }
     }
     const int S = (int)seg_first.size();
-    std::vector<int> ev_slot(n_ev), ev_mesh(n_ev);
-    std::vector<float> ev_v((size_t)n_ev * 12);
-    for (int j = 0; j < n_ev; j++) { ev_slot[j] = events[j].slot; ev_mesh[j] = events[j].mesh; memcpy(&ev_v[(size_t)j * 12], events[j].v, 48); }
-
-    DevBuf<int> d_rec_node, d_rec_j, d_rec_child, d_rec_changed, d_seg_first, d_seg_count, d_ev_slot, d_ev_mesh, d_out_count, d_out_node;
-    DevBuf<float> d_rec_box, d_ev_v, d_out_bytes;
-    if (!d_rec_node.alloc(R) || !d_rec_j.alloc(R) || !d_rec_child.alloc(R) || !d_rec_changed.alloc(R) || !d_seg_first.alloc(S) ||
-        !d_seg_count.alloc(S) || !d_ev_slot.alloc(n_ev) || !d_ev_mesh.alloc(n_ev) || !d_out_count.alloc(1) || !d_out_node.alloc(S) ||
-        !d_rec_box.alloc((size_t)R * 6) || !d_ev_v.alloc((size_t)n_ev * 12) || !d_out_bytes.alloc((size_t)S * 8)) { err = "out of device memory"; return false; }
-    CK(hipMemcpyAsync(d_rec_node.p, rec_node.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
-    CK(hipMemcpyAsync(d_rec_j.p, rec_j.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
-    CK(hipMemcpyAsync(d_rec_child.p, rec_child.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
-    CK(hipMemcpyAsync(d_seg_first.p, seg_first.data(), sizeof(int) * S, hipMemcpyHostToDevice, st));
-    CK(hipMemcpyAsync(d_seg_count.p, seg_count.data(), sizeof(int) * S, hipMemcpyHostToDevice, st));
-    CK(hipMemcpyAsync(d_ev_slot.p, ev_slot.data(), sizeof(int) * n_ev, hipMemcpyHostToDevice, st));
-    CK(hipMemcpyAsync(d_ev_mesh.p, ev_mesh.data(), sizeof(int) * n_ev, hipMemcpyHostToDevice, st));
-    CK(hipMemcpyAsync(d_ev_v.p, ev_v.data(), sizeof(float) * 12 * n_ev, hipMemcpyHostToDevice, st));
-    CK(hipMemsetAsync(d_out_count.p, 0, sizeof(int), st));
+    // device scratch, one block: [inputs: rec_node R | rec_j R | rec_child R | seg_first S | seg_count S | ev_slot n | ev_mesh n |
+    // ev_v 12 n | wide_list W] [outputs: out_count 1 | out_node S | out_bytes 8 S] [rec_changed R | rec_box 6 R]; the host block mirrors
+    // the inputs for the upload and the outputs for the download
+    // per level: its segments that go to k_refit_level_wide
+    std::vector<int> wide_list, wide_first(level_first_seg.size() + 1, 0);
+    for (size_t l = 0; l < level_first_seg.size(); l++) {
+        for (int q = level_first_seg[l]; q < level_first_seg[l] + level_n_segs[l]; q++) {
+            const int k = kind[rec_node[seg_first[q]]];
+            if (seg_count[q] >= REFIT_WIDE && k != N_SOCKET && k != N_LEAF) wide_list.push_back(q);
+        }
+        wide_first[l + 1] = (int)wide_list.size();
+    }
+    const size_t W = wide_list.size();
+    const size_t in_words = (size_t)3 * R + 2 * (size_t)S + 14 * (size_t)n_ev + W, out_words = 1 + 9 * (size_t)S, tmp_words = 7 * (size_t)R;
+    const size_t d_need = (in_words + out_words + tmp_words) * 4, h_need = std::max(in_words, out_words) * 4;
+    if (d_need > d_ws_bytes) {
+        if (d_ws) { (void)hipFree(d_ws); d_ws = nullptr; }
+        d_ws_bytes = 0;
+        if (hipMalloc(&d_ws, d_need * 2) != hipSuccess) { err = "out of device memory"; return false; }
+        d_ws_bytes = d_need * 2;
+    }
+    if (h_need > h_ws_bytes) {
+        if (h_ws) { (void)hipHostFree(h_ws); h_ws = nullptr; }
+        h_ws_bytes = 0;
+        if (hipHostMalloc(&h_ws, h_need * 2) != hipSuccess) { err = "out of pinned host memory"; return false; }
+        h_ws_bytes = h_need * 2;
+    }
+    int* const d_in = (int*)d_ws;
+    int* const d_rec_node = d_in; int* const d_rec_j = d_rec_node + R; int* const d_rec_child = d_rec_j + R;
+    int* const d_seg_first = d_rec_child + R; int* const d_seg_count = d_seg_first + S;
+    int* const d_ev_slot = d_seg_count + S; int* const d_ev_mesh = d_ev_slot + n_ev;
+    float* const d_ev_v = (float*)(d_ev_mesh + n_ev);
+    int* const d_wide = (int*)(d_ev_v + (size_t)12 * n_ev);
+    int* const d_out = d_in + in_words;
+    int* const d_out_count = d_out; int* const d_out_node = d_out + 1; float* const d_out_bytes = (float*)(d_out + 1 + S);
+    int* const d_rec_changed = d_out + out_words; float* const d_rec_box = (float*)(d_rec_changed + R);
+    {
+        int* h = (int*)h_ws;
+        memcpy(h, rec_node.data(), sizeof(int) * R); h += R;
+        memcpy(h, rec_j.data(), sizeof(int) * R); h += R;
+        memcpy(h, rec_child.data(), sizeof(int) * R); h += R;
+        memcpy(h, seg_first.data(), sizeof(int) * S); h += S;
+        memcpy(h, seg_count.data(), sizeof(int) * S); h += S;
+        for (int j = 0; j < n_ev; j++) h[j] = events[j].slot;
+        h += n_ev;
+        for (int j = 0; j < n_ev; j++) h[j] = events[j].mesh;
+        h += n_ev;
+        for (int j = 0; j < n_ev; j++) memcpy(h + (size_t)j * 12, events[j].v, 48);
+        h += (size_t)12 * n_ev;
+        if (W) memcpy(h, wide_list.data(), sizeof(int) * W);
+    }
+    lap("packed");
+    CK(hipMemcpyAsync(d_in, h_ws, in_words * 4, hipMemcpyHostToDevice, st));
+    CK(hipMemsetAsync(d_out_count, 0, sizeof(int), st));
     RefitArgs A;
     A.first_child = d_first_child; A.n_children = d_n_children; A.kind = d_kind; A.slot_first = d_slot_first; A.slot_count = d_slot_count;
     A.mesh_of_socket = d_mesh_of_socket; A.node_id = d_node_id; A.xform = d_xform; A.rec_off = d_rec_off; A.rec_cnt = d_rec_cnt;
     A.raw_box = d_raw_box; A.obj_box = d_obj_box; A.xf12 = d_xf12;
-    A.rec_node = d_rec_node.p; A.rec_j = d_rec_j.p; A.rec_child = d_rec_child.p; A.rec_changed = d_rec_changed.p; A.rec_box = d_rec_box.p;
-    A.seg_first = d_seg_first.p; A.seg_count = d_seg_count.p; A.ev_slot = d_ev_slot.p; A.ev_mesh = d_ev_mesh.p; A.ev_v = d_ev_v.p;
-    A.out_count = d_out_count.p; A.out_node = d_out_node.p; A.out_bytes = d_out_bytes.p;
-    hipLaunchKernelGGL(k_refit_index, dim3((S + 127) / 128), dim3(128), 0, st, d_seg_first.p, d_seg_count.p, d_rec_node.p, S, d_rec_off, d_rec_cnt);
+    A.rec_node = d_rec_node; A.rec_j = d_rec_j; A.rec_child = d_rec_child; A.rec_changed = d_rec_changed; A.rec_box = d_rec_box;
+    A.seg_first = d_seg_first; A.seg_count = d_seg_count; A.ev_slot = d_ev_slot; A.ev_mesh = d_ev_mesh; A.ev_v = d_ev_v;
+    A.out_count = d_out_count; A.out_node = d_out_node; A.out_bytes = d_out_bytes;
+    hipLaunchKernelGGL(k_refit_index, dim3((S + 127) / 128), dim3(128), 0, st, d_seg_first, d_seg_count, d_rec_node, S, d_rec_off, d_rec_cnt);
     CK(hipGetLastError());
     for (size_t l = 0; l < level_first_seg.size(); l++) {  // deepest level first
         hipLaunchKernelGGL(k_refit_level, dim3((level_n_segs[l] + 63) / 64), dim3(64), 0, st, A, level_first_seg[l], level_n_segs[l]);
         CK(hipGetLastError());
+        if (wide_first[l + 1] > wide_first[l]) {
+            hipLaunchKernelGGL(k_refit_level_wide, dim3((unsigned)(wide_first[l + 1] - wide_first[l])), dim3(256), 0, st, A, d_wide + wide_first[l]);
+            CK(hipGetLastError());
+        }
     }
     hipLaunchKernelGGL(k_refit_commit, dim3((S + 127) / 128), dim3(128), 0, st, A, S);
     CK(hipGetLastError());
-    int n_out = 0;
-    CK(hipMemcpyAsync(&n_out, d_out_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    // count, node list and records come back in one copy (at most one record per node that had an edit on its path)
+    lap("launched");
+    CK(hipMemcpyAsync(h_ws, d_out, out_words * 4, hipMemcpyDeviceToHost, st));
     CK(hipStreamSynchronize(st));
+    lap("done");
+    const int* h_out = (const int*)h_ws;
+    const int n_out = h_out[0];
+    if (n_out < 0 || n_out > S) { err = "refit: bad record count"; return false; }
     if (n_out > 0) {
-        nodes_out.resize(n_out);
+        nodes_out.assign(h_out + 1, h_out + 1 + n_out);
         bytes_out.resize((size_t)n_out * 32);
-        CK(hipMemcpyAsync(nodes_out.data(), d_out_node.p, sizeof(int) * n_out, hipMemcpyDeviceToHost, st));
-        CK(hipMemcpyAsync(bytes_out.data(), d_out_bytes.p, (size_t)n_out * 32, hipMemcpyDeviceToHost, st));
-        CK(hipStreamSynchronize(st));
+        memcpy(bytes_out.data(), h_out + 1 + S, (size_t)n_out * 32);
     }
     return true;
 }
