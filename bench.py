@@ -441,7 +441,10 @@ def main():
             "workload": workload,
             "width": WIDTH, "height": HEIGHT, "triangles": N_TRIANGLES, "max_ray_depth": DEPTH,
             "max_refraction_bounces": REFRACTION_BOUNCES, "rays_per_step": rays_local / args.steps,
-            "bvh_nodes": len(disp.packed.bvh) // 32, "bvh_build_s": build_s,
+            "bvh_nodes": len(disp.packed.bvh) // 32,
+            # the library's own time for the scene's trees (ptk_bvh_build calls; ptk_bvh_bind), and the whole scene set-up
+            # of this script around it (Python packers of the records, uploads)
+            "bvh_build_s": disp.bvh_library_seconds[0], "bvh_bind_s": disp.bvh_library_seconds[1], "scene_setup_s": build_s,
             "parallelism": "sample batches per GPU, scene replicated, RCCL reduce of accumulators" if world > 1 else "single GPU",
         },
         "ranks": ranks,

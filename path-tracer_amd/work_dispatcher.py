@@ -9,6 +9,7 @@ product's DeviceBvhBuilder runs the HIP builder of libptk.
 from __future__ import annotations
 
 import struct
+import time
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -172,9 +173,13 @@ class DeviceBvhBuilder:
 
     def __init__(self, rd: PtkRenderingDevice):
         self.rd = rd
+        self.library_seconds = 0.0  # wall time spent inside ptk_bvh_build (mesh trees and scene tree together)
 
     def build(self, order, bvh_type, aabbs6, object_ids, mesh_bvhs=(), mesh_transforms12=None, mesh_indices=None):
-        return self.rd.bvh_build(order, bvh_type, aabbs6, object_ids, mesh_bvhs, mesh_transforms12, mesh_indices)
+        t0 = time.perf_counter()
+        tree = self.rd.bvh_build(order, bvh_type, aabbs6, object_ids, mesh_bvhs, mesh_transforms12, mesh_indices)
+        self.library_seconds += time.perf_counter() - t0
+        return tree
 
     def read(self, handle):
         return self.rd.bvh_read(handle)
@@ -302,6 +307,7 @@ class PTWorkDispatcher:
         self.image_buffer = 0
         self.material_buffer = self.sphere_buffer = self.plane_buffer = self.triangle_buffer = 0
         self.bvh_buffer = self.object_id_buffer = self.transform_buffer = 0
+        self.bvh_library_seconds = (0.0, 0.0)
         self.triangle_vertex_buffer = self.triangle_uv_buffer = self.triangle_index_buffer = 0
 
     def set_scene(self, scene: sc.PTScene):
@@ -328,7 +334,10 @@ class PTWorkDispatcher:
             builder = DeviceBvhBuilder(self.rd)
             tree, mesh_trees = build_scene_tree(self._scene, builder, order, bvh_type)
             if tree is not None:
+                t0 = time.perf_counter()
                 bound = self.rd.bvh_bind(tree)
+                # what the library itself took for the scene's trees: ptk_bvh_build calls, ptk_bvh_bind
+                self.bvh_library_seconds = (builder.library_seconds, time.perf_counter() - t0)
                 builder.release(tree, mesh_trees)  # the bound tree keeps what it needs for refits
                 n_nodes, n_ids = self.rd.bvh_sizes_of_bound(bound)
                 nodes = self.rd.buffer_get_data(bound[0], 0, n_nodes * NODE_BYTE_SIZE)

@@ -19,7 +19,9 @@ out = {
     "workload": old["workload"],
     "source_hash": bench.kernel_source_hash(),
     "kernel": "ptk_wf_traverse",
-    "command": old["command"],
+    "command": "rocprofv3 --pmc <group> -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-configs, one pass per counter "
+               "group (tools/pmc_passes.sh); the averages are over every launch of the kernel in those runs, the short last "
+               "launches of a step included: FETCH_SIZE; WRITE_SIZE TCC_HIT_sum TCC_MISS_sum; SQ_*; TA_/TD_/TCP_/GRBM_",
     "launches_averaged": r["F"]["FETCH_SIZE"]["dispatches"],
     "fetch_size_kb_per_launch": fetch_kb,
     "write_size_kb_per_launch": write_kb,
