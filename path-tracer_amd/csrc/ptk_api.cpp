@@ -167,6 +167,10 @@ struct ptk_ctx {
     int lds_window = 20;           // traversal stack entries per lane kept in LDS, deeper ones spill to a global column
                                    // (PTK_LDS_WINDOW, read once at create; what the stacks leave of a compute unit's LDS holds
                                    // the top node blocks: 12 / 16 / 20 / 24 / 32 rows gave 8.53 / 7.76 / 7.62 / 7.63 / 7.69 ms per step)
+    int wf_parts = 1;              // parts of a launch's queue (PTK_WF_PARTS=8: one per XCD, see PtkWavefront::n_parts; read once at create).
+                                   // Measured on the 262 144-triangle scene: 8 parts 8.07 ms per sample against 7.50 with one head; the L2 hit
+                                   // rate is the same (0.603 / 0.597), the launches are 8 % longer with the gather path less busy: the parts
+                                   // differ in work and the workgroups end up on one another's parts late.
     bool wf_carry = true;          // the pipeline parks unfinished searches for the next launch (PTK_WF_CARRY=0 turns it off; read once at create)
     int wf_max_lag = 2, wf_park_below = 16;  // (PTK_WF_MAX_LAG, PTK_WF_PARK_BELOW: tuning, read once at create)
     int leaf_redo_all = 0;         // (PTK_LEAF_REDO_ALL=1: exercises trav_leaf's fallback on every helped leaf; for tests)
@@ -259,6 +263,7 @@ ptk_ctx* ptk_create(int device_ordinal) {
     const int max_window = (int)((PTK_LDS_BYTES_PER_CU - PTK_WF_WG_FLAG_BYTES) / (PTK_WF_WG_WAVES * 256)) - 1;
     if (const char* w = getenv("PTK_LDS_WINDOW")) ctx->lds_window = std::max(8, std::min(max_window, atoi(w)));
     if (const char* w = getenv("PTK_WF_CARRY")) ctx->wf_carry = atoi(w) != 0;
+    if (const char* w = getenv("PTK_WF_PARTS")) ctx->wf_parts = atoi(w) >= PTK_WF_MAX_PARTS ? PTK_WF_MAX_PARTS : 1;
     if (const char* w = getenv("PTK_DEVICE_DERIVE")) ctx->device_derive = atoi(w) != 0 ? 1 : 0;
     if (const char* w = getenv("PTK_WF_MAX_LAG")) ctx->wf_max_lag = std::max(1, std::min(PTK_WF_MAX_LAG, atoi(w)));
     if (const char* w = getenv("PTK_WF_PARK_BELOW")) ctx->wf_park_below = std::max(1, std::min(64, atoi(w)));
@@ -1728,16 +1733,19 @@ int ptk_dispatch(ptk_ctx* ctx, const void* push128, int groups_x, int groups_y, 
         if (ctx->d_wf) { (void)hipFree(ctx->d_wf); ctx->d_wf = nullptr; }
         ctx->wf_slots = 0;
         const size_t per_slot = 2 * 32 + 2 * 32 + 16 + 8 + 40 + 2 * PTK_WF_PREP_PLANES * 4;  // rays x2, state x2, hits, hit uv, inside arrays, started searches x2
-        HIP_TRY(ctx, hipMalloc(&ctx->d_wf, n_slots * per_slot + 1024));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_wf, n_slots * per_slot + PTK_WF_HEADER_BYTES));
         ctx->wf_slots = n_slots;
     }
     {
         uint8_t* base = (uint8_t*)ctx->d_wf;
         const size_t cap = ctx->wf_slots;
-        P.wf.counts = (uint32_t*)base;                       // counts then heads, zeroed per dispatch
-        P.wf.heads = P.wf.counts + (PTK_WF_MAX_ITER + 1);
-        P.wf.n_resume = P.wf.heads + (PTK_WF_MAX_ITER + 1);
-        base += 1024;
+        P.wf.counts = (uint32_t*)base;                       // counts, parked counts, heads: zeroed per dispatch
+        P.wf.n_resume = P.wf.counts + (PTK_WF_MAX_ITER + 1);
+        P.wf.heads = P.wf.counts + 192;                      // (PTK_WF_MAX_ITER + 1) * PTK_WF_MAX_PARTS words
+        static_assert((192 + (PTK_WF_MAX_ITER + 1) * PTK_WF_MAX_PARTS) * 4 <= PTK_WF_HEADER_BYTES, "queue header too small");
+        static_assert(2 * (PTK_WF_MAX_ITER + 1) + 1 <= 192, "counts and parked counts overlap the heads");
+        P.wf.n_parts = (uint32_t)ctx->wf_parts;
+        base += PTK_WF_HEADER_BYTES;
         P.wf.rays[0] = (float4*)base; base += cap * 32;
         P.wf.rays[1] = (float4*)base; base += cap * 32;
         P.wf.state[0] = (float4*)base; base += cap * 32;
@@ -1943,7 +1951,14 @@ extern "C" int ptk_dev_wf_counts(ptk_ctx* ctx, uint32_t* out256) {
     if (!ctx || !out256 || !ctx->d_wf) return PTK_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out256, ctx->d_wf, 1024, hipMemcpyDeviceToHost));
+    uint32_t h[PTK_WF_HEADER_BYTES / 4];
+    HIP_TRY(ctx, hipMemcpy(h, ctx->d_wf, sizeof h, hipMemcpyDeviceToHost));
+    memset(out256, 0, 1024);
+    for (int i = 0; i <= PTK_WF_MAX_ITER; i++) {
+        out256[i] = h[i];
+        out256[130 + i] = h[PTK_WF_MAX_ITER + 1 + i];
+        for (int p = 0; p < PTK_WF_MAX_PARTS; p++) out256[65 + i] += h[192 + i * PTK_WF_MAX_PARTS + p];
+    }
     return PTK_OK;
 }
 

@@ -48,7 +48,10 @@ struct PtkTexDesc {
 #ifndef PTK_PP_MAX_WG_WAVES
 #define PTK_PP_MAX_WG_WAVES 12  // waves of a path-kernel workgroup (three per SIMD at its register count)
 #endif
-#define PTK_WF_WG_FLAG_BYTES 16 // LDS words the waves of a workgroup share besides the top blocks: queue dry, waves done, the claim word (wg_claim)
+#define PTK_WF_WG_FLAG_BYTES 32 // LDS words the waves of a workgroup share besides the top blocks: queue dry, waves done, the claim word (wg_claim),
+                                // the part of the queue the workgroup draws from
+#define PTK_WF_HEADER_BYTES 4096 // counts, n_resume and the queue heads (one per part and launch) in front of the queues, zeroed per dispatch
+#define PTK_WF_MAX_PARTS 8
 #define PTK_WF_CARRY_PLANES 25 // words of search state carried besides the stack rows
 #define PTK_WF_PREP_PLANES 10  // words of a started search (PtkWavefront::prep; wf_prepare in ptk_wavefront.hip)
 // The top of many trees is a chain every ray walks in the same way: a root with one child, a mesh socket, a
@@ -73,7 +76,14 @@ struct PtkWavefront {
     int4* hits;
     float2* hit_uv;
     uint32_t* counts;  // counts[i] = rays the shading of launch i-1 queued for launch i (PTK_WF_MAX_ITER + 1 words)
-    uint32_t* heads;   // heads[i]  = rays of launch i handed to waves               (PTK_WF_MAX_ITER + 1 words)
+    uint32_t* heads;   // heads[i * PTK_WF_MAX_PARTS + p] = entries of part p of launch i's queue handed to workgroups
+                       // ((PTK_WF_MAX_ITER + 1) * PTK_WF_MAX_PARTS words; the path kernel: one word, its pixel counter)
+    // Optional (default: one part).  The queue of a launch is cut into n_parts equal parts (1 or 8), each with a head of its own.  A workgroup draws
+    // from part blockIdx.x % 8 -- workgroups are dealt round-robin over the chip's eight XCDs, so the workgroups that
+    // share an L2 share a part, i.e. a stretch of the queue and with it (queues keep the order of the pixel slots they
+    // stem from) a region of the image and of the scene -- and goes on to the next part when its own is used up.  Eight
+    // heads also spread the device-wide atomics, which complete one at a time per address.
+    uint32_t n_parts;
     // Carry-over: when the queue of launch i runs dry, a wave does not sit out the searches it still has in
     // flight but parks them -- ray, path state, search state, stack -- at the front of launch i+1's queue
     // (entries [0, n_resume[i+1])), where full waves pick them up again.  A launch then ends when its queue

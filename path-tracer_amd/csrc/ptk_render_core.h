@@ -276,7 +276,11 @@ PTK_DEV int st_read(const Stack& s, int i) {
 // wave that finds the device-wide counter past `count` leaves that as a mark in the word.
 enum : int { CLAIM_OK = 0, CLAIM_LATER = 1, CLAIM_DRY = 2 };
 // `grab` (at most 64, a divisor of wg_chunk) is what a wave takes at a time.
-PTK_DEV int wg_claim(unsigned long long* range, uint32_t* head, uint32_t wg_chunk, uint32_t count, int lane, uint32_t& c_next, uint32_t& c_end, uint32_t grab = 64u) {
+// Parts: with n_parts > 1 the queue is [0, count) in n_parts stretches of part_len entries (a multiple of wg_chunk),
+// head[p] counts what has been taken from stretch p, and *cur_part (LDS, one word per workgroup, set to the workgroup's
+// own part at the start) is the stretch the workgroup draws from; a stretch that is used up sends it to the next.
+PTK_DEV int wg_claim(unsigned long long* range, uint32_t* head, uint32_t wg_chunk, uint32_t count, int lane, uint32_t& c_next, uint32_t& c_end, uint32_t grab = 64u,
+                     uint32_t n_parts = 1u, uint32_t part_len = 0u, volatile int __attribute__((address_space(3))) * cur_part = nullptr) {
     uint32_t nx = 0, en = 0;
     if (lane == 0) {
         const unsigned long long old = __hip_atomic_fetch_add(range, (unsigned long long)grab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -286,7 +290,18 @@ PTK_DEV int wg_claim(unsigned long long* range, uint32_t* head, uint32_t wg_chun
     en = __builtin_amdgcn_readfirstlane(en);
     if (nx == en) {
         uint32_t base = count;  // (no counter: the workgroup's one chunk was set at the start, and this is its end)
-        if (head) {
+        if (head && n_parts > 1u) {
+            if (lane == 0) {
+                uint32_t p = (uint32_t)*cur_part;
+                for (uint32_t tries = 0; tries < n_parts; tries++) {
+                    const uint32_t off = atomicAdd(head + p, wg_chunk);
+                    if (off < part_len && p * part_len + off < count) { base = p * part_len + off; break; }
+                    p = p + 1u < n_parts ? p + 1u : 0u;
+                }
+                *cur_part = (int)p;
+            }
+            base = __builtin_amdgcn_readfirstlane(base);
+        } else if (head) {
             if (lane == 0) base = atomicAdd(head, wg_chunk);
             base = __builtin_amdgcn_readfirstlane(base);
         }

@@ -244,7 +244,8 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
             top[(i >> 4) * (PTK_TOP_BLOCK_STRIDE / 16) + (i & 15u)] = W.blocks[i];
         if (threadIdx.x < PTK_WF_WG_FLAG_BYTES / 4) {
             int v = 0;
-            if (dealt && threadIdx.x >= 2) v = (int)((blockIdx.x + (threadIdx.x - 2)) * chunk);  // [2] next = the chunk's start, [3] its end
+            if (dealt && (threadIdx.x == 2 || threadIdx.x == 3)) v = (int)((blockIdx.x + (threadIdx.x - 2)) * chunk);  // [2] next = the chunk's start, [3] its end
+            if (threadIdx.x == 4) v = (int)(blockIdx.x % W.n_parts);  // [4] the part of the queue this workgroup draws from
             lds_all[W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64 + threadIdx.x] = v;
         }
         __syncthreads();  // the only workgroup-wide step: from here on every wave runs on its own
@@ -256,6 +257,8 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
     typedef volatile int __attribute__((address_space(3))) * LdsFlags;
     const LdsFlags wg_flags = (LdsFlags)(lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64);
     unsigned long long* const wg_range = (unsigned long long*)(lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + PTK_WF_WG_WAVES * (P.lds_cap + 1) * 64 + 2);  // see wg_claim
+    // parts of the queue (PtkWavefront::n_parts): equal stretches of whole chunks
+    const uint32_t part_len = (count + W.n_parts * chunk - 1u) / (W.n_parts * chunk) * chunk;
     Stack S;
     S.top = (PtkLdsBlocks)lds_all; S.n_top = W.n_top;
     S.lds = lds_all + W.n_top * (PTK_TOP_BLOCK_STRIDE / 4) + wave * (P.lds_cap + 1) * 64;
@@ -307,7 +310,8 @@ __global__ __launch_bounds__(PTK_WF_WG_WAVES * 64) void ptk_wf_traverse(const Pt
                 const unsigned long long need = __ballot(!have);
                 if (need == 0ull) break;
                 if (c_next == c_end) {
-                    const int got = wg_claim(wg_range, dealt ? nullptr : W.heads + iter, chunk, count, lane, c_next, c_end, grab);
+                    const int got = wg_claim(wg_range, dealt ? nullptr : W.heads + iter * PTK_WF_MAX_PARTS, chunk, count, lane, c_next, c_end, grab,
+                                             W.n_parts, part_len, (volatile int __attribute__((address_space(3)))*)wg_flags + 4);
                     if (got == CLAIM_DRY) { exhausted = true; if (lane == 0) wg_flags[0] = 1; break; }
                     if (got == CLAIM_LATER) { __builtin_amdgcn_s_sleep(1); break; }  // another wave is fetching the workgroup's next chunk
                 }
@@ -535,7 +539,7 @@ extern "C" hipError_t ptk_wavefront_occupancy(size_t lds_bytes, int* wgs_per_cu)
 extern "C" hipError_t ptk_launch_wavefront(const PtkParams* p, int gx, int gy, int n_iter, size_t lds_bytes,
                                            int n_wgs, hipEvent_t* ev, hipStream_t stream) {
     const unsigned blocks = (unsigned)gx * (unsigned)gy;
-    hipError_t e = hipMemsetAsync(p->wf.counts, 0, 1024, stream);  // counts, heads (and development counters)
+    hipError_t e = hipMemsetAsync(p->wf.counts, 0, PTK_WF_HEADER_BYTES, stream);  // counts, parked counts, heads
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ptk_wf_generate, dim3(blocks), dim3(64), 0, stream, *p);
     for (int it = 0; it < n_iter; it++) {

@@ -203,6 +203,8 @@ def test_helped_leaves_handed_back(pta, golden_dir, monkeypatch):
     {"PTK_LDS_WINDOW": "12", "PTK_LEAF_SPLIT": "7"},
     {"PTK_LDS_WINDOW": "64"},  # more than sixteen waves' windows fit a compute unit: held to what does
     {"PTK_LDS_WINDOW": "32"},
+    {"PTK_WF_PARTS": "8", "PTK_WF_WG_CLAIM": "64"},  # a queue head per XCD, workgroups moving on to the next part
+    {"PTK_WF_PARTS": "8", "PTK_WF_CARRY": "0"},
 ], ids=lambda e: ",".join(f"{k[4:].lower()}={v}" for k, v in e.items()))
 def test_pipeline_tuning_variables_do_not_change_the_image(pta, golden_dir, monkeypatch, env):
     """The pipeline's scheduling knobs (chunk of the queue a workgroup takes, when and how far behind searches are
