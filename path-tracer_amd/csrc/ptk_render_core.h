@@ -475,7 +475,11 @@ PTK_DEV Hit check_ray_hit_bvh(const PtkParams& P, Lane& L, Ray& ray, const Stack
 // wave no longer pays the inner-node code and the leaf code in every iteration.  The next node to
 // visit stays in a register (`cur`): the nearest accepted child is not pushed and popped again.
 #ifndef PTK_VOTE_INNER
-#define PTK_VOTE_INNER(ni, nl) (2 * (ni) >= 3 * (nl))
+#ifndef PTK_VOTE_NUM
+#define PTK_VOTE_NUM 3
+#define PTK_VOTE_DEN 2
+#endif
+#define PTK_VOTE_INNER(ni, nl) (PTK_VOTE_DEN * (ni) >= PTK_VOTE_NUM * (nl))
 #endif
 constexpr uint32_t ENTRY_NONE = 0x7E000000u;  // "inner node with 126 children": never a real entry
 

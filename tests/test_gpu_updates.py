@@ -286,3 +286,42 @@ def test_launches_follow_the_materials(pta, golden_dir):
         d.free_rids()
     finally:
         dev.close()
+
+
+def test_a_primitive_that_turns_to_glass_brings_the_launches_back(pta, golden_dir):
+    """The same bound on the launches as above, reached from the primitives' side: a scene whose glass material no sphere
+    uses is rendered with max_default_depth launches; one sphere record rewritten to use it (a patched edit, no
+    re-validation) makes paths refract again, and the launches for their extra bounces return."""
+    wd = pta.work_dispatcher
+    scene = pta.scenes.load_fixture_scene("sphere_scene1", golden_dir)
+    packed = copy.copy(wd.pack_scene(scene, ob.OracleBvhBuilder(), 8))
+    n_mats, n_sph = len(packed.materials) // 64, len(packed.spheres) // 32
+    glass = [m for m in range(1, n_mats) if struct.unpack_from("<f", packed.materials, m * 64 + 20)[0] < 1.0]
+    opaque = [m for m in range(1, n_mats) if m not in glass][0]
+    users = [i for i in range(n_sph) if struct.unpack_from("<i", packed.spheres, i * 32 + 16)[0] in glass
+             and struct.unpack_from("<f", packed.spheres, i * 32 + 12)[0] > 0]
+    assert glass and users
+    for i in users:
+        _edit(packed, "spheres", i * 32 + 16, struct.pack("<i", opaque))
+    w, h = 320, 184
+    dev = pta.PtkRenderingDevice(0)
+    try:
+        dev.set_renderer(pta.rendering_device.PTK_RENDERER_WAVEFRONT)
+        d = wd.PTWorkDispatcher(dev)
+        d.create_buffers(w, h, packed=packed)
+        d.load_shader()
+        win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=5, max_refraction_bounces=4)
+        cpu = np.zeros((h, w, 4), np.float32)
+        devs = [("pipeline", dev, d)]
+        _render_all(pta, devs, packed, scene, win, 0, cpu)
+        assert len(dev.dispatch_traverse_ms(0)) == 5
+        validations = dev.update_stats()[0]
+        data = struct.pack("<i", glass[0])
+        _edit(packed, "spheres", users[0] * 32 + 16, data)
+        dev.buffer_update(d.sphere_buffer, users[0] * 32 + 16, 4, data)
+        _render_all(pta, devs, packed, scene, win, 1, cpu)
+        assert len(dev.dispatch_traverse_ms(0)) == 5 + 3
+        assert dev.update_stats()[0] == validations
+        d.free_rids()
+    finally:
+        dev.close()
