@@ -58,6 +58,15 @@ def _scenes(pta, golden_dir):
     yield "atrium_20000", scene, wd.pack_scene(scene, ob.OracleBvhBuilder(), 8)
     scene, packed = deep_chain_scene(pta, depth=9)
     yield "deep_chain", scene, packed
+    # nothing in the tree at all (an all-zero root, 8 bytes of id table), and a lone sphere (the root is a leaf)
+    scene = pta.scene.PTScene()
+    scene.add_object(pta.scene.PTPlane(normal=(0.0, 1.0, 0.0), distance=-1.0))
+    scene.camera = pta.scene.PTCamera()
+    yield "planes_only", scene, wd.pack_scene(scene, ob.OracleBvhBuilder(), 8)
+    scene = pta.scene.PTScene()
+    scene.add_object(pta.scene.PTSphere())
+    scene.camera = pta.scene.PTCamera()
+    yield "one_sphere", scene, wd.pack_scene(scene, ob.OracleBvhBuilder(), 8)
 
 
 def test_device_and_host_derive_the_same_tree(pta, golden_dir, monkeypatch):
