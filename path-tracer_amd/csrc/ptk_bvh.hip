@@ -161,6 +161,54 @@ DEV void sort_emit(Seg part, Seg* small, int* small_count, Seg* big, int* big_co
 // SortArray::sort's depth budget: 2 * bitlog(length)
 DEV int sort_depth_budget(int len) { return 2 * (31 - __clz(len)); }
 
+// ---- summaries of a long list's batches ------------------------------------------------------------
+// The merge chain of a list runs in list order on one wave (k_list_box below), 64 elements to a batch, and in a long
+// unordered list almost every batch moves neither end of the box: it is passed over once a few comparisons have shown
+// that -- every element's position above the box's, every far end below the box's, every size non-negative and not
+// all three zero.  Those comparisons only need the batch's smallest position and largest far end per axis, which do
+// not depend on the chain: they are made here, by as many waves as the chip has, so that the one wave of the chain
+// reads 32 bytes per batch instead of gathering its 64 boxes.  summary[b] = {min position xyz, max far end xyz,
+// shape ok (every size >= 0, not all three zero, nothing NaN), -}; mesh sockets among the full batches are counted
+// into call_meshes[c].  Only full batches have a summary; a list's last, partial batch is always worked on in full.
+constexpr int LIST_SUMMARY_MIN = 2048;  // lists at least this long get summaries
+__global__ __launch_bounds__(256) void k_list_summary(const Call* calls, int n_calls, const int* summ_off, const int* perm, const float* in_aabb,
+                                                      const int* in_kind, float* summary, int* call_meshes) {
+    const int c = blockIdx.x;
+    if (c >= n_calls) return;
+    const int off = summ_off[c];
+    if (off < 0) return;
+    const Call call = calls[c];
+    const int n_full = (call.end - call.begin) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int meshes = 0;
+    for (int b = blockIdx.y * 4 + wave; b < n_full; b += gridDim.y * 4) {
+        const int id = perm[call.begin + b * 64 + lane];
+        const A6 m = a6_load(in_aabb, id);
+        meshes += __popcll(__ballot(in_kind[id] == 1));
+        float lo[3], hi[3];
+        bool ok = !(m.s[0] == 0.0f && m.s[1] == 0.0f && m.s[2] == 0.0f);
+        for (int a = 0; a < 3; a++) {
+            lo[a] = m.p[a];
+            hi[a] = m.p[a] + m.s[a];
+            ok = ok && m.s[a] >= 0.0f && lo[a] == lo[a] && hi[a] == hi[a];
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            for (int a = 0; a < 3; a++) {
+                const float l2 = __shfl_xor(lo[a], o), h2 = __shfl_xor(hi[a], o);
+                lo[a] = l2 < lo[a] ? l2 : lo[a];
+                hi[a] = h2 > hi[a] ? h2 : hi[a];
+            }
+        }
+        const bool all_ok = __all(ok);
+        if (lane == 0) {
+            float* q = summary + (size_t)(off + b) * 8;
+            q[0] = lo[0]; q[1] = lo[1]; q[2] = lo[2]; q[3] = hi[0]; q[4] = hi[1]; q[5] = hi[2];
+            q[6] = all_ok ? 1.0f : 0.0f; q[7] = 0.0f;
+        }
+    }
+    if (lane == 0 && meshes) atomicAdd(call_meshes + c, meshes);
+}
+
 // ---- per-call kernels (one wave per call) ------------------------------------------------------
 // list box: sequential merge chain in list order (get_array_aabb, pt_bvh_axis_sort.gd:512-516), then
 // .abs().grow(1e-6) (:277); also counts mesh sockets and picks the axis (:279-280).
@@ -168,7 +216,8 @@ DEV int sort_depth_budget(int len) { return 2 * (31 - __clz(len)); }
 // (counters sort_now) and clears the counters the next level will use (sort_next).
 __global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls, const int* perm, const float* in_aabb,
                                                  const int* in_kind, int type, int fixed_axis, CallOut* out, Seg* sort_small,
-                                                 Seg* sort_big, int* sort_now, int* sort_next) {
+                                                 Seg* sort_big, int* sort_now, int* sort_next,
+                                                 const int* summ_off, const float* summary, const int* call_meshes) {
     __shared__ __align__(16) float tr[6][64];
     int c = blockIdx.x;
     if (c >= n_calls) return;
@@ -316,6 +365,45 @@ __global__ __launch_bounds__(64) void k_list_box(const Call* calls, int n_calls,
         }
         note_box();
     };
+    const int s_off = summ_off ? summ_off[c] : -1;
+    if (s_off >= 0) {
+        // A long list: its full batches by their summaries (k_list_summary).  A batch is passed over exactly when the
+        // test at the head of `batch` would pass it over -- the box settled, the batch's shape ok, its smallest
+        // position above the box's and its largest far end below the box's on every axis (what holds for the
+        // extremes holds for all 64) -- and is gathered and worked on otherwise.  Sockets were counted with the summaries.
+        const int n_full = (call.end - call.begin) / 64;
+        meshes = call_meshes[c];
+        for (int b0 = 0; b0 < n_full; b0 += 64) {
+            const int bj = b0 + lane;
+            const bool has = bj < n_full;
+            float4 sa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sb = sa;
+            if (has) { const float4* q = reinterpret_cast<const float4*>(summary + (size_t)(s_off + bj) * 8); sa = q[0]; sb = q[1]; }
+            const int n_here = min(64, n_full - b0);
+            int w = 0;
+            while (w < n_here) {
+                if (settled) {
+                    const bool quiet = has && sb.z != 0.0f && sa.x > acc.p[0] && sa.y > acc.p[1] && sa.z > acc.p[2] &&
+                                       sa.w < far_x && sb.x < far_y && sb.y < far_z;
+                    // the run of quiet batches from w on
+                    const unsigned long long loud = ~__ballot(quiet) >> w;
+                    w += loud == 0ull ? 64 - w : __builtin_ctzll(loud);
+                    if (w >= n_here) break;
+                }
+                // (gathering the next such batch while this one's chain runs measured no faster: the chain is what is left)
+                const int base = call.begin + (b0 + w) * 64;
+                batch(base, a6_load(in_aabb, perm[base + lane]), 0);
+                w++;
+            }
+        }
+        const int tail = call.begin + n_full * 64;
+        if (tail < call.end) {
+            const int i = tail + lane;
+            A6 mine = a6_zero();
+            int kind = 0;
+            if (i < call.end) { const int id = perm[i]; mine = a6_load(in_aabb, id); kind = in_kind[id]; }
+            batch(tail, mine, kind);
+        }
+    } else
     for (int base0 = call.begin; base0 < call.end; base0 += 64 * LIST_UNROLL) {
         A6 cur[LIST_UNROLL];
         int cur_kind[LIST_UNROLL];
@@ -1140,6 +1228,12 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
                 const float* mesh_transforms12, std::string& err) {
     const int N = T.n_objects, M = (int)T.meshes.size(), n_in = N + M;
     T.n_in = n_in;
+    const bool timing = getenv("PTK_BUILD_TIMING") != nullptr;  // (development aid: where a build's host time goes, on stderr)
+    const auto t_begin = std::chrono::steady_clock::now();
+    double t_wait = 0.0;  // of which: waiting for the GPU at the levels' ends
+    auto lap = [&](const char* what) {
+        if (timing) fprintf(stderr, "build %-12s %.3f ms (waits so far %.3f)\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), t_wait);
+    };
     if (!T.in_aabb.alloc((size_t)n_in * 6) || !T.in_kind.alloc(n_in) || !T.in_ref.alloc(n_in) || !T.perm.alloc(n_in)) { err = "out of device memory"; return false; }
     std::vector<int> kind(n_in, 0), ref(n_in, -1);
     for (int i = 0; i < N; i++) ref[i] = object_ids[i];
@@ -1238,6 +1332,9 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
         DevBuf<Call> d_calls;
         DevBuf<CallOut> d_out;
         DevBuf<int> d_slices;  // per-slice bin counts of k_bins
+        DevBuf<float> d_summary;           // k_list_summary: 8 words per full batch of the level's long lists
+        DevBuf<int> d_summ_off, d_call_meshes;
+        if (!d_summary.alloc(((size_t)n_in / 64 + 1) * 8)) { err = "out of device memory"; return false; }
         SortWorkspace ws;
         if (!ws.counters.alloc(2 * SORT_COUNTERS)) { err = "out of device memory"; return false; }
         CK(hipMemsetAsync(ws.counters.p, 0, sizeof(int) * 2 * SORT_COUNTERS, st));
@@ -1278,8 +1375,27 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
             const int set = depth & 1;
             if (!d_calls.alloc(nc) || !d_out.alloc(nc) || (sorts && !ws.reserve(covered, n_in, any_big))) { err = "out of device memory"; return false; }
             CK(hipMemcpyAsync(d_calls.p, hc.data(), sizeof(Call) * nc, hipMemcpyHostToDevice, st));
+            // long lists: their batches' summaries first, by many waves (k_list_summary), for the one wave of the chain
+            const bool summaries = longest >= LIST_SUMMARY_MIN;
+            std::vector<int> soff;  // (lives until the level's wait, like hc)
+            if (summaries) {
+                soff.assign(nc, -1);
+                int run = 0;
+                for (int i = 0; i < nc; i++) {
+                    const int len = calls[i].end - calls[i].begin;
+                    if (len >= LIST_SUMMARY_MIN) { soff[i] = run; run += len / 64; }
+                }
+                if (!d_summ_off.alloc(nc) || !d_call_meshes.alloc(nc)) { err = "out of device memory"; return false; }
+                CK(hipMemcpyAsync(d_summ_off.p, soff.data(), sizeof(int) * nc, hipMemcpyHostToDevice, st));
+                CK(hipMemsetAsync(d_call_meshes.p, 0, sizeof(int) * nc, st));
+                const int sy = std::max(1, std::min(256, (longest / 64 + 15) / 16));  // four waves a block, four batches a wave at least
+                hipLaunchKernelGGL(k_list_summary, dim3(nc, sy), dim3(256), 0, st, d_calls.p, nc, d_summ_off.p, T.perm.p, T.in_aabb.p, T.in_kind.p,
+                                   d_summary.p, d_call_meshes.p);
+                CK(hipGetLastError());
+            }
             hipLaunchKernelGGL(k_list_box, dim3(nc), dim3(64), 0, st, d_calls.p, nc, T.perm.p, T.in_aabb.p, T.in_kind.p, T.type, fixed_axis, d_out.p,
-                               sorts ? ws.small.p : nullptr, ws.big_a.p, ws.counters.p + set * SORT_COUNTERS, ws.counters.p + (set ^ 1) * SORT_COUNTERS);
+                               sorts ? ws.small.p : nullptr, ws.big_a.p, ws.counters.p + set * SORT_COUNTERS, ws.counters.p + (set ^ 1) * SORT_COUNTERS,
+                               summaries ? d_summ_off.p : nullptr, d_summary.p, d_call_meshes.p);
             CK(hipGetLastError());
             std::vector<CallOut> ho(nc);
             if (sorts) {
@@ -1304,7 +1420,11 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
                 CK(hipGetLastError());
             }
             CK(hipMemcpyAsync(ho.data(), d_out.p, sizeof(CallOut) * nc, hipMemcpyDeviceToHost, st));
-            CK(hipStreamSynchronize(st));
+            {
+                const auto w0 = std::chrono::steady_clock::now();
+                CK(hipStreamSynchronize(st));
+                t_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+            }
             std::vector<int> segc(nc, T.order);
             std::vector<unsigned char> mv(nc, 0);  // calls that moved elements: those with more than one non-empty bin (:314-325)
             for (int i = 0; i < nc; i++) {
@@ -1359,6 +1479,7 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
         }
     }
     CK(hipStreamSynchronize(st));
+    lap("levels");
 
     // terminal bins of lists that contain sockets: sockets become children in list order, the objects
     // go to one leaf child that is added last (pt_bvh_axis_sort.gd:349-369).  These lists are tiny.
@@ -1423,6 +1544,7 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
     T.own_object_count = 0;
     for (int l : T.leaf_order) T.own_object_count += T.nodes[l].obj_count;
 
+    lap("leaf order");
     // boxes: leaves, sockets, then inner nodes bottom-up
     const int nn = (int)T.nodes.size();
     if (!T.node_aabb.alloc((size_t)nn * 6)) { err = "out of device memory"; return false; }
@@ -1499,6 +1621,7 @@ bool build_tree(hipStream_t st, BvhImpl& T, const float* aabbs6, const int32_t* 
         }
         CK(hipStreamSynchronize(st));
     }
+    lap("boxes");
     return true;
 }
 
