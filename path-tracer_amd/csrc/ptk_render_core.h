@@ -1292,20 +1292,22 @@ PTK_DEV Ray bounce_ray(const PtkParams& P, Lane& L, const Ray& ray_in, Surf& s) 
         if (L.refraction_bounces < P.push.max_refraction_bounces - 1) L.refraction_bounces++;
         return new_ray(offset_ray(s.point, -normal), refract3(ray_in.d, normal, eta));
     }
+    // reflect_ray (:1340-1359) and scatter_ray (:1324-1338) start alike -- the origin moved off the surface, one random
+    // point on the sphere (each draws it once, as its first and only use of the generator) -- so the metallic and the
+    // diffuse lanes of a wave run that part together instead of one kind after the other
+    const f3 new_origin = offset_ray(s.point, normal);
+    const f3 sphere_point = random_point_on_sphere(L);
+    f3 ray_dir;
     if (metallic > 0.0f) {
-        // reflect_ray, :1340-1359
-        f3 new_origin = offset_ray(s.point, normal);
-        f3 reflected_dir = reflect3(ray_in.d, normal) * metallic;
-        f3 dir_offset = random_point_on_sphere(L) * (1.0f - metallic);
-        f3 ray_dir = reflected_dir + dir_offset;
+        const f3 reflected_dir = reflect3(ray_in.d, normal) * metallic;
+        const f3 dir_offset = sphere_point * (1.0f - metallic);
+        ray_dir = reflected_dir + dir_offset;
         if (dot3(ray_dir, normal) < 0.0f) ray_dir = reflect3(ray_dir, normal);
-        return new_ray(new_origin, ray_dir);
+    } else {
+        ray_dir = sphere_point + normal;
+        if (near_zero3(ray_dir)) ray_dir = normal;
+        if (dot3(ray_dir, normal) < 0.0f) ray_dir = ray_dir * -1.0f;
     }
-    // scatter_ray, :1324-1338
-    f3 new_origin = offset_ray(s.point, normal);
-    f3 ray_dir = random_point_on_sphere(L) + normal;
-    if (near_zero3(ray_dir)) ray_dir = normal;
-    if (dot3(ray_dir, normal) < 0.0f) ray_dir = ray_dir * -1.0f;
     return new_ray(new_origin, ray_dir);
 }
 
