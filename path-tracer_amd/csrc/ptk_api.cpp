@@ -92,6 +92,9 @@ struct ptk_ctx {
     bool wf_ok = false;            // scene has no mesh socket below another mesh socket
     float4* d_blocks = nullptr;    // compiled inner nodes, 256 bytes each (see PtkWavefront)
     size_t d_blocks_bytes = 0, d_sockets_bytes = 0;  // allocated sizes of d_blocks / d_sockets
+    float4* d_inv_xf = nullptr;    // inverse of every matrix of the transform buffer (PtkParams::inv_transforms)
+    size_t d_inv_xf_bytes = 0;
+    bool inv_xf_dirty = false;     // a matrix was edited: the table is made again with the next flush
     int2* d_sockets = nullptr;
     float root_box[6] = {0};
     uint32_t root_entry = 0;
@@ -302,6 +305,7 @@ void ptk_destroy(ptk_ctx* ctx) {
     if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
     if (ctx->d_sockets) (void)hipFree(ctx->d_sockets);
     if (ctx->d_derive) (void)hipFree(ctx->d_derive);
+    if (ctx->d_inv_xf) (void)hipFree(ctx->d_inv_xf);
     if (ctx->d_leaf_records) (void)hipFree(ctx->d_leaf_records);
     if (ctx->d_wf) (void)hipFree(ctx->d_wf);
     if (ctx->d_wf_spill) (void)hipFree(ctx->d_wf_spill);
@@ -774,6 +778,12 @@ static int flush_updates(ptk_ctx* ctx) {
         HIP_TRY(ctx, ptk_launch_scatter(ctx->d_stage[k], (uint32_t)n_ent, ctx->stream));
         i = j;
     }
+    if (ctx->inv_xf_dirty) {  // (behind the scatter that brought the edited matrices to the device)
+        Object* xfb = bound_buffer(ctx, PTK_SET_TRANSFORM, 0);
+        if (xfb && ctx->d_inv_xf && xfb->nbytes <= ctx->d_inv_xf_bytes)
+            HIP_TRY(ctx, ptk_launch_inverse_transforms(xfb->dev, (int)(xfb->nbytes / 64), ctx->d_inv_xf, ctx->stream));
+        ctx->inv_xf_dirty = false;
+    }
     ctx->flushes++;
     return PTK_OK;
 }
@@ -836,7 +846,7 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
         last = std::min(last, o->nbytes / rec_bytes);
     };
     if (o->set == PTK_SET_OBJECT && o->binding == 0) { refresh_may_refract(ctx); return 1; }  // materials: only whether paths can refract
-    if (o->set == PTK_SET_TRANSFORM) { derive_chain(ctx); return 1; }  // (a chain step holds its matrix by value)
+    if (o->set == PTK_SET_TRANSFORM) { derive_chain(ctx); ctx->inv_xf_dirty = true; return 1; }  // (a chain step holds its matrix by value)
     if (o->set == PTK_SET_TRIANGLE || o->set == PTK_SET_TEXTURE) return 1;
     if (o->set == PTK_SET_OBJECT && o->binding == 2) {  // planes
         size_t a, b;
@@ -1374,6 +1384,15 @@ static int validate_scene(ptk_ctx* ctx) {
     }
     if (n_ids == 0) HIP_TRY(ctx, hipMemsetAsync(ctx->d_leaf_records, 0, 48, ctx->stream));
     HIP_TRY(ctx, ptk_launch_leaf_records((const int32_t*)ids->dev, n_ids, tri->dev, n_tri, sph->dev, n_sph, ctx->d_leaf_records, ctx->stream));
+    // the inverse of every mesh matrix (the kernels read it where the shader computes inverse(mat4) per hit)
+    if ((size_t)std::max(n_xf, 1) * 64 > ctx->d_inv_xf_bytes) {
+        if (ctx->d_inv_xf) { (void)hipFree(ctx->d_inv_xf); ctx->d_inv_xf = nullptr; }
+        ctx->d_inv_xf_bytes = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_inv_xf, (size_t)std::max(n_xf, 1) * 64));
+        ctx->d_inv_xf_bytes = (size_t)std::max(n_xf, 1) * 64;
+    }
+    HIP_TRY(ctx, ptk_launch_inverse_transforms(xf->dev, n_xf, ctx->d_inv_xf, ctx->stream));
+    ctx->inv_xf_dirty = false;
 
     // the derived structures were uploaded whole: nothing of them is pending any more
     ctx->dirty_blocks.clear();
@@ -1481,6 +1500,7 @@ static int fill_params(ptk_ctx* ctx, const void* push128, PtkParams& P) {
     P.planes = (const float4*)pln->dev;
     P.triangles = (const float4*)tri->dev;
     P.transforms = (const float4*)xf->dev;
+    P.inv_transforms = ctx->d_inv_xf;
     P.live_planes = ctx->d_live_planes;
     P.n_live_planes = ctx->n_live_planes;
     P.n_arg_planes = -1;

@@ -136,6 +136,8 @@ struct PtkParams {
     const float4* triangles;   // 5 float4 per 80-byte record
     const float4* materials;   // 4 float4 per 64-byte record
     const float4* transforms;  // 4 float4 per 64-byte matrix
+    const float4* inv_transforms;  // inverse44 of each of them (the shader takes inverse(mat4) at every instanced hit,
+                                   // ray_tracer.comp:1021, 1065: the same arithmetic, done once per matrix when it changes)
     const float* triangle_uvs; // PTK_OPT_TRIANGLE_UVS: 6 floats per triangle record (corner UVs) from (4,1), else null
     int n_triangle_uvs;
     const int* live_planes;    // indices of plane records with a non-zero normal
@@ -259,6 +261,8 @@ extern "C" hipError_t ptk_launch_derive_levels(const PtkDerive* d, int n_levels,
 extern "C" hipError_t ptk_launch_derive_number(const PtkDerive* d, uint32_t n_reached, hipStream_t stream);
 extern "C" hipError_t ptk_launch_derive_fill(const PtkDerive* d, uint32_t n_reached, float* blocks, int32_t* sockets, hipStream_t stream);
 
+// inverse44 of n 64-byte matrices (ptk_update.hip), into PtkParams::inv_transforms.
+extern "C" hipError_t ptk_launch_inverse_transforms(const void* xf64, int n, void* out64, hipStream_t stream);
 // Leaf records (48 bytes per object-id slot) from the bound id table, triangle and sphere buffers, all on the device.
 extern "C" hipError_t ptk_launch_leaf_records(const int32_t* ids, int n_ids, const void* triangles80, int n_tri, const void* spheres32, int n_sph,
                                               void* out48, hipStream_t stream);

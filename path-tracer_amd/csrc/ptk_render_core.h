@@ -115,6 +115,14 @@ PTK_DEV m44 load_xform(const PtkParams& P, int i) {
     return m;
 }
 
+// inverse(mat4) of transform i (:1021, 1065), from the table made when the matrices were bound or edited
+PTK_DEV m44 load_inv_xform(const PtkParams& P, int i) {
+    m44 m;
+    const float4* p = P.inv_transforms + (size_t)i * 4;
+    m.c0 = p[0]; m.c1 = p[1]; m.c2 = p[2]; m.c3 = p[3];
+    return m;
+}
+
 // slab test, :670-689.  The swap is the shader's arithmetic swap (a=a+b; b=a-b; a=a-b).
 PTK_DEV float hit_aabb(float4 bmin, float4 bmax, f3 o, f3 inv, int neg_mask, float start, float end) {
     float t0, t1;
@@ -1107,7 +1115,7 @@ PTK_DEV Surf determine_rayhit(const PtkParams& P, Lane& L, const Ray& ray_in, co
         bool need_uv = (s.texture_id >> 30) != 0u || (s.texture_id & 0x3fffffffu) != 0u;
         if (h.transform_index >= 0) {
             m44 m = load_xform(P, h.transform_index);
-            m44 matrix = inverse44(m);
+            m44 matrix = load_inv_xform(P, h.transform_index);
             f3 td = mul_mv(m, ray_in.d, 0.0f);
             f3 to = mul_mv(m, ray_in.o, 1.0f);
             f3 usn = normalize3((to + td * ray_in.end) - center);
@@ -1139,7 +1147,7 @@ PTK_DEV Surf determine_rayhit(const PtkParams& P, Lane& L, const Ray& ray_in, co
         s.point = (p2 * h.u + p3 * h.v) + p1 * w;
         if (h.transform_index >= 0) {
             m44 m = load_xform(P, h.transform_index);
-            m44 matrix = inverse44(m);
+            m44 matrix = load_inv_xform(P, h.transform_index);
             s.normal = normalize3(mul_vm(s.normal, 0.0f, m));
             s.point = mul_mv(matrix, s.point, 1.0f);
         }

@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "ptk_device.h"
+#include "ptk_math.h"
 
 // one workgroup per entry; destinations of one batch never overlap (the host merges ranges)
 __global__ __launch_bounds__(256) void ptk_scatter_kernel(const uint8_t* __restrict__ stage, uint32_t n_entries) {
@@ -62,5 +63,22 @@ extern "C" hipError_t ptk_launch_leaf_records(const int32_t* ids, int n_ids, con
     if (n_ids <= 0) return hipSuccess;
     hipLaunchKernelGGL(ptk_leaf_records_kernel, dim3((n_ids + 255) / 256), dim3(256), 0, stream, ids, n_ids, (const float4*)triangles80, n_tri,
                        (const float4*)spheres32, n_sph, (float4*)out48);
+    return hipGetLastError();
+}
+
+// The inverse of every mesh matrix, by the function the render kernels would otherwise run at each instanced hit
+// (inverse44 in ptk_math.h: the same operations in the same order, so the same bits).
+__global__ __launch_bounds__(64) void ptk_inverse_transforms_kernel(const float4* __restrict__ xf, int n, float4* __restrict__ out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    m44 m;
+    m.c0 = xf[(size_t)i * 4]; m.c1 = xf[(size_t)i * 4 + 1]; m.c2 = xf[(size_t)i * 4 + 2]; m.c3 = xf[(size_t)i * 4 + 3];
+    const m44 r = inverse44(m);
+    out[(size_t)i * 4] = r.c0; out[(size_t)i * 4 + 1] = r.c1; out[(size_t)i * 4 + 2] = r.c2; out[(size_t)i * 4 + 3] = r.c3;
+}
+
+extern "C" hipError_t ptk_launch_inverse_transforms(const void* xf64, int n, void* out64, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ptk_inverse_transforms_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, (const float4*)xf64, n, (float4*)out64);
     return hipGetLastError();
 }
