@@ -6,7 +6,7 @@ PTObject.get_bvh_aabb (pt_object.gd:269-272) over a surface decoded the way Godo
 RenderingServer.mesh_surface_get_arrays decodes it.  Godot's source is not part of the reference checkout:
 the decode rule (unorm16 positions relative to the surface aabb under ARRAY_FLAG_COMPRESS_ATTRIBUTES, 16-bit
 indices up to 65536 vertices, attribute block = [colour][uv][uv2]) is restated from its published format and
-is pinned only by plausibility of the decoded meshes (triangle counts of the survey, closed surfaces):
+is pinned only by plausibility of the decoded meshes (index counts that match the scene files, closed surfaces):
 parity unpinned against Godot itself.  Imported by tests/ only."""
 import numpy as np
 
