@@ -150,33 +150,46 @@ __global__ __launch_bounds__(64) PTK_TILE_WAVES(BLOCKS) void ptk_render_kernel(c
 #ifdef PTK_TILE_HWID  // measurement builds: where and when the tile ran (the cost array has room for three words a tile)
         const uint32_t n_tiles = gridDim.x * gridDim.y;
         P.tile_cost[n_tiles + tile] = (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) & 0xFFFFu) | (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16);
+#ifdef PTK_TILE_WGID  // ... or which workgroup of the launch it was (its place in the order)
+        P.tile_cost[2 * n_tiles + tile] = wg;
+#else
         P.tile_cost[2 * n_tiles + tile] = (uint32_t)tile_t0;
+#endif
 #endif
     }
 }
 
-// Tiles in the order the next dispatch should start them: by the power of two of the time they took in the last
-// one, the longest first.  A counting sort over 33 classes by one workgroup; a wave places 64 consecutive tiles at
-// a time, so tiles of one class stay in runs of neighbours (which share rays' nodes in the caches), and when all
-// tiles fall into two adjacent classes the frame is even enough to be left in its own order.  The order changes
-// when a tile runs, not what it computes.
+// Tiles in the order the next dispatch should start them: by the time they took in the last one, the longest first.
+// A counting sort by one workgroup over classes an eighth of an octave wide (the exponent of the cost and its top three
+// mantissa bits); a wave places 64 consecutive tiles at a time, so tiles of one class stay in runs of neighbours (which
+// share rays' nodes in the caches), and when all tiles fall into two adjacent octaves the frame is even enough to be
+// left in its own order.  Fine classes matter for where the longest tiles run: workgroups w, w + 1024, w + 2048 and
+// w + 3072 of a launch start on the same SIMD (observed), so with the tiles in order of cost every SIMD begins with one
+// of the 1024 longest, one of the next 1024 and so on, instead of several of the longest taking turns on one SIMD while
+// others run dry.  The order changes when a tile runs, not what it computes.
+constexpr int TILE_CLASSES = 33 * 8;
+__device__ inline int tile_cost_class(uint32_t cost) {
+    if (cost == 0u) return 0;
+    const int lz = __clz(cost);
+    return ((32 - lz) << 3) | (int)(((cost << lz) >> 28) & 7u);
+}
 __global__ __launch_bounds__(1024) void ptk_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ order) {
-    __shared__ uint32_t count[33], start[33];
+    __shared__ uint32_t count[TILE_CLASSES], start[TILE_CLASSES];
     __shared__ int even;
     const int lane = threadIdx.x & 63;
-    if (threadIdx.x < 33) count[threadIdx.x] = 0;
+    if (threadIdx.x < TILE_CLASSES) count[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) atomicAdd(&count[cost[i] ? 32 - __clz(cost[i]) : 0], 1u);
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) atomicAdd(&count[tile_cost_class(cost[i])], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t at = 0;
-        int lo = 33, hi = -1;
-        for (int c = 32; c >= 0; c--) {
+        int lo = TILE_CLASSES, hi = -1;
+        for (int c = TILE_CLASSES - 1; c >= 0; c--) {
             start[c] = at;
             at += count[c];
             if (count[c]) { lo = c; if (hi < 0) hi = c; }
         }
-        even = hi - lo <= 1;
+        even = (hi >> 3) - (lo >> 3) <= 1;
     }
     __syncthreads();
     if (even) {
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(1024) void ptk_tile_order_kernel(const uint32_t* __
     }
     for (uint32_t i0 = (threadIdx.x >> 6) * 64; i0 < n; i0 += 1024) {  // (uniform over the wave)
         const uint32_t i = i0 + lane;
-        const int c = i < n ? (cost[i] ? 32 - __clz(cost[i]) : 0) : -1;
+        const int c = i < n ? tile_cost_class(cost[i]) : -1;
         unsigned long long todo = __ballot(c >= 0);
         while (todo) {
             const int cls = __builtin_amdgcn_readlane(c, __builtin_ctzll(todo));
