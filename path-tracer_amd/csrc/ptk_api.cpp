@@ -813,6 +813,18 @@ static int ensure_mirrors(ptk_ctx* ctx) {
     return PTK_OK;
 }
 
+// The words 0..2, 4..11 of a triangle's leaf record from its 80-byte record, as ptk_leaf_records_kernel makes them:
+// A, E1 = B - A with N.x, E2 = C - A with N.y (N = E1 x E2), each by one rounded operation per step.
+static void triangle_leaf_words(float* r, const uint8_t* p80) {
+    float a[3], b[3], c[3];
+    memcpy(a, p80, 12); memcpy(b, p80 + 16, 12); memcpy(c, p80 + 32, 12);
+    const float e1x = b[0] - a[0], e1y = b[1] - a[1], e1z = b[2] - a[2];
+    const float e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2];
+    r[4] = e1x; r[5] = e1y; r[6] = e1z; r[7] = e1y * e2z - e2y * e1z;
+    r[8] = e2x; r[9] = e2y; r[10] = e2z; r[11] = e1z * e2x - e2z * e1x;
+}
+
 static void mark_material_used(ptk_ctx* ctx, int32_t m) {
     if (m >= 0 && (size_t)m < ctx->mat_used.size()) ctx->mat_used[m] = 1;
     else ctx->may_refract = true;  // (an index validation will refuse; nothing to conclude from it)
@@ -883,7 +895,7 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
             int32_t oid = 0;  // the slot's word of the id table
             if (Object* idt = bound_buffer(ctx, PTK_SET_BVH, 1)) { if ((size_t)slot * 4 + 4 <= idt->shadow.size()) memcpy(&oid, idt->shadow.data() + (size_t)slot * 4, 4); }
             memset(r, 0, 48);
-            if (tri) { memcpy(r + 0, p + 0, 12); memcpy(r + 4, p + 16, 12); memcpy(r + 8, p + 32, 12); }
+            if (tri) triangle_leaf_words(r, p);
             else { memcpy(r + 0, p, 12); memcpy(r + 4, p + 12, 4); }
             memcpy(r + 3, &oid, 4);
             if (!ctx->slot_is_dirty[slot]) { ctx->slot_is_dirty[slot] = 1; ctx->dirty_slots.push_back((uint32_t)slot); }
@@ -977,7 +989,7 @@ static int patch_derived(ptk_ctx* ctx, Object* o, size_t offset, size_t nbytes, 
             if (type == 3) {
                 if ((size_t)oi >= ctx->tri_slot.size()) return 0;
                 const uint8_t* p = tri->shadow.data() + (size_t)oi * 80;
-                memcpy(r + 0, p + 0, 12); memcpy(r + 4, p + 16, 12); memcpy(r + 8, p + 32, 12);
+                triangle_leaf_words(r, p);
                 { int32_t m; memcpy(&m, p + 64, 4); mark_material_used(ctx, m); }
                 ctx->tri_slot[oi] = ctx->tri_slot[oi] == -1 ? (int32_t)i : -2;
                 ctx->leaves_hold_triangles = true;

@@ -207,6 +207,25 @@ PTK_DEV void hit_triangle_rec(Ray& ray, Hit& h, int object_id, int cur_xf, f3 A,
         ray.end = tt;
     }
 }
+// The same test on a leaf record (PtkWavefront::leaf_records): E1, E2 and the first two components of N = E1 x E2 come
+// with the record, made by these very operations when the record was.
+PTK_DEV void hit_triangle_pre(Ray& ray, Hit& h, int object_id, int cur_xf, f3 A, f3 E1, f3 E2, float Nx, float Ny) {
+    f3 N = mk3(Nx, Ny, E1.x * E2.y - E2.x * E1.y);
+    float det = -dot3(ray.d, N);
+    if (near_zero1(det)) return;
+    float invdet = 1.0f / det;
+    f3 AO = ray.o - A;
+    float tt = dot3(AO, N) * invdet;
+    if (!in_range(tt, ray.start, ray.end)) return;
+    f3 DAO = cross3(AO, ray.d);
+    float u = dot3(E2, DAO) * invdet;
+    float v = -dot3(E1, DAO) * invdet;
+    if (u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f) {
+        h.hit = 1; h.object_id = object_id; h.transform_index = cur_xf;
+        h.u = u; h.v = v;
+        ray.end = tt;
+    }
+}
 template <bool TRACE>
 PTK_DEV void hit_triangle_mt(const PtkParams& P, Ray& ray, Hit& h, int object_id, int cur_xf, int* cnt) {
     const float4* t = P.triangles + (size_t)bfe_i(object_id, 0, 24) * 5;
@@ -908,7 +927,7 @@ PTK_DEV bool trav_inner(const PtkParams& P, const Stack& S, Trav& T) {
 
 // Objects [first, first + count) of a leaf against ray r, in order (:1137-1142), for every lane of the wave with
 // its own span; the loop runs to the longest span among them.  Leaf records: {A.xyz | centre.xyz, object id},
-// {B.xyz | radius, -}, {C.xyz, -}, stored in object-id-slot order.
+// {E1.xyz, N.x | radius, -}, {E2.xyz, N.y | -}, stored in object-id-slot order.
 PTK_DEV void leaf_span(const PtkParams& P, int first, int count, int cur_xf, Ray& r, Hit& h, bool* either_root) {
     const float4* __restrict__ rec = P.wf.leaf_records + (size_t)first * 3;
 #ifdef PTK_LEAF_NO_PREFETCH
@@ -919,7 +938,7 @@ PTK_DEV void leaf_span(const PtkParams& P, int first, int count, int cur_xf, Ray
             const float4 r0 = rec[k * 3], r1 = rec[k * 3 + 1], r2 = rec[k * 3 + 2];
             const int object_id = (int)fbits(r0.w);
             const int type = bfe_i(object_id, 24, 8);
-            if (type == IS_TRIANGLE) hit_triangle_rec(r, h, object_id, cur_xf, ld3(r0), ld3(r1), ld3(r2));
+            if (type == IS_TRIANGLE) hit_triangle_pre(r, h, object_id, cur_xf, ld3(r0), ld3(r1), ld3(r2), r1.w, r2.w);
             else if (type == IS_SPHERE) hit_sphere_rec(r, h, object_id, cur_xf, ld3(r0), r1.x, either_root);
         }
     }
@@ -945,7 +964,7 @@ PTK_DEV void leaf_span(const PtkParams& P, int first, int count, int cur_xf, Ray
             if (go) {
                 const int object_id = (int)fbits(q[i][0].w);
                 const int type = bfe_i(object_id, 24, 8);
-                if (type == IS_TRIANGLE) hit_triangle_rec(r, h, object_id, cur_xf, ld3(q[i][0]), ld3(q[i][1]), ld3(q[i][2]));
+                if (type == IS_TRIANGLE) hit_triangle_pre(r, h, object_id, cur_xf, ld3(q[i][0]), ld3(q[i][1]), ld3(q[i][2]), q[i][1].w, q[i][2].w);
                 else if (type == IS_SPHERE) hit_sphere_rec(r, h, object_id, cur_xf, ld3(q[i][0]), q[i][1].x, either_root);
             }
         }

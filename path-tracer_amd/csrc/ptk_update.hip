@@ -35,9 +35,12 @@ extern "C" hipError_t ptk_launch_scatter(const void* d_stage, uint32_t n_entries
 }
 
 // Leaf records: what a leaf tests for object-id slot i, by value, so that the traversal reads a leaf's primitives
-// from consecutive addresses without going through the id table first.  Triangle: {A.xyz, id} {B.xyz, 0} {C.xyz, 0}
-// from the 80-byte record (pt_triangle.gd:125-150); sphere: {centre.xyz, id} {radius, 0, 0, 0} {0} from the 32-byte
-// record; anything else (and an index outside its buffer, which validation has refused by then) zeros.
+// from consecutive addresses without going through the id table first.  Triangle, from the 80-byte record
+// (pt_triangle.gd:125-150): {A.xyz, id} {E1.xyz, N.x} {E2.xyz, N.y} with E1 = B - A, E2 = C - A, N = E1 x E2 -- the
+// first steps of the shader's triangle test (ray_tracer.comp:926-969), which do not depend on the ray and are made here
+// once, by the same operations (hit_triangle_pre in ptk_render_core.h takes them up; N.z fits no word and is made
+// there).  Sphere: {centre.xyz, id} {radius, 0, 0, 0} {0} from the 32-byte record; anything else (and an index outside
+// its buffer, which validation has refused by then) zeros.
 __global__ __launch_bounds__(256) void ptk_leaf_records_kernel(const int32_t* __restrict__ ids, int n_ids, const float4* __restrict__ triangles,
                                                                int n_tri, const float4* __restrict__ spheres, int n_sph, float4* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -47,9 +50,11 @@ __global__ __launch_bounds__(256) void ptk_leaf_records_kernel(const int32_t* __
     float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
     if (type == 3 && oi >= 0 && oi < n_tri) {
         const float4 a = triangles[(size_t)oi * 5], b = triangles[(size_t)oi * 5 + 1], c = triangles[(size_t)oi * 5 + 2];
+        const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
+        const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
         r0 = make_float4(a.x, a.y, a.z, __int_as_float(oid));
-        r1 = make_float4(b.x, b.y, b.z, 0.0f);
-        r2 = make_float4(c.x, c.y, c.z, 0.0f);
+        r1 = make_float4(e1x, e1y, e1z, e1y * e2z - e2y * e1z);
+        r2 = make_float4(e2x, e2y, e2z, e1z * e2x - e2z * e1x);
     } else if (type == 1 && oi >= 0 && oi < n_sph) {
         const float4 s = spheres[(size_t)oi * 2];
         r0 = make_float4(s.x, s.y, s.z, __int_as_float(oid));
