@@ -1432,6 +1432,7 @@ static int validate_scene(ptk_ctx* ctx) {
     ctx->dirty = false;
     ctx->full_validations++;
     ctx->scene_version++;
+    ctx->tile_gx = ctx->tile_gy = 0;  // the tile kernel's order of tiles was measured on another scene: the next dispatch measures anew
     ctx->last_validate_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return PTK_OK;
 }
