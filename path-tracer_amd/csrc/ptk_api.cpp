@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cfenv>
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
@@ -814,8 +815,15 @@ static int ensure_mirrors(ptk_ctx* ctx) {
 }
 
 // The words 0..2, 4..11 of a triangle's leaf record from its 80-byte record, as ptk_leaf_records_kernel makes them:
-// A, E1 = B - A with N.x, E2 = C - A with N.y (N = E1 x E2), each by one rounded operation per step.
+// A, E1 = B - A with N.x, E2 = C - A with N.y (N = E1 x E2), each by one rounded operation per step.  The only
+// floating-point arithmetic the host does for an image: it runs in the default environment (round to nearest, denormals
+// kept), whatever the calling thread has set, so that it gives what the device kernel gives.
 static void triangle_leaf_words(float* r, const uint8_t* p80) {
+    struct DefaultFenv {
+        fenv_t saved;
+        DefaultFenv() { fegetenv(&saved); fesetenv(FE_DFL_ENV); }
+        ~DefaultFenv() { fesetenv(&saved); }
+    } in_default_environment;
     float a[3], b[3], c[3];
     memcpy(a, p80, 12); memcpy(b, p80 + 16, 12); memcpy(c, p80 + 32, 12);
     const float e1x = b[0] - a[0], e1y = b[1] - a[1], e1z = b[2] - a[2];
