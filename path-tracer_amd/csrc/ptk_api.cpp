@@ -1957,7 +1957,8 @@ int ptk_dev_wf_ends(ptk_ctx* ctx, unsigned long long* out, size_t n) {
 // host's and the device's derivation.  kind 0: blocks (64 words each), 1: socket table (2 words a row), 2: node ->
 // child slot, 3: triangle -> id slot, 4: sphere -> id slot, 5: {stack need, top blocks, blocks, sockets, block
 // traversal covers the scene, levels the device pass walked (0: host), root entry, paths may refract, leaves hold
-// triangles, device derivations so far, host microseconds of the last validation}.  *n = words there are; at most `capacity` are copied.
+// triangles, device derivations so far, host microseconds of the last validation}, 6: leaf records (12 words per id slot).
+// *n = words there are; at most `capacity` are copied.
 extern "C" int ptk_dev_read_derived(ptk_ctx* ctx, int kind, uint32_t* out, size_t capacity, size_t* n) {
     if (!ctx || !n || ctx->dirty) return PTK_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1982,6 +1983,13 @@ extern "C" int ptk_dev_read_derived(ptk_ctx* ctx, int kind, uint32_t* out, size_
         info[7] = ctx->may_refract ? 1u : 0u; info[8] = ctx->leaves_hold_triangles ? 1u : 0u; info[9] = (uint32_t)ctx->device_derivations;
         info[10] = (uint32_t)(ctx->last_validate_ms * 1000.0);
         words = 11; host = info; break;
+    case 6: {  // the leaf records, 12 words per object-id slot (pending patches are flushed first, as a dispatch would)
+        { int r = flush_updates(ctx); if (r != PTK_OK) return r; }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        Object* ids = bound_buffer(ctx, PTK_SET_BVH, 1);
+        if (!ids || !ctx->d_leaf_records) return PTK_E_STATE;
+        words = std::min(ids->nbytes / 4, ctx->d_leaf_records_slots) * 12; dev = ctx->d_leaf_records; break;
+    }
     default: return PTK_E_INVALID;
     }
     *n = words;

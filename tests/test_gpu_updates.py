@@ -325,3 +325,71 @@ def test_a_primitive_that_turns_to_glass_brings_the_launches_back(pta, golden_di
         d.free_rids()
     finally:
         dev.close()
+
+
+def _leaf_records(dev):
+    import ctypes as C
+    dev.lib.ptk_dev_read_derived.restype = C.c_int
+    dev.lib.ptk_dev_read_derived.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    n = C.c_size_t(0)
+    assert dev.lib.ptk_dev_read_derived(dev.ctx, 6, None, 0, C.byref(n)) == 0
+    out = np.zeros(n.value, np.uint32)
+    assert dev.lib.ptk_dev_read_derived(dev.ctx, 6, out.ctypes.data, n.value, C.byref(n)) == 0
+    return out.reshape(-1, 12)
+
+
+def test_triangle_patches_do_not_depend_on_the_callers_rounding_mode(pta, rd_wf, golden_dir):
+    """A triangle rewritten with buffer_update gets the ray-independent part of its test (edges, normal components) from
+    host arithmetic.  The calling thread rounds toward zero while it makes the edits: the patched leaf records must be,
+    bit for bit, what the device kernel derives from the same bytes when the scene is bound anew (the image is a weak
+    witness here: a last-bit change of a normal rarely changes which object a path hits)."""
+    import ctypes
+    import ctypes.util
+    libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    FE_TONEAREST, FE_TOWARDZERO = 0x000, 0xC00  # <fenv.h>, x86-64
+    wd = pta.work_dispatcher
+    scene = pta.scenes.load_fixture_scene("dragon_test", golden_dir)
+    packed = copy.copy(wd.pack_scene(scene, ob.OracleBvhBuilder(), 8))
+    w, h = 320, 184
+    d = wd.PTWorkDispatcher(rd_wf)
+    d.create_buffers(w, h, packed=packed)
+    d.load_shader()
+    devs = [(rd_wf.pinned, rd_wf, d)]
+    win = wd.PTRenderWindow(render_width=w, render_height=h, max_ray_depth=5, max_refraction_bounces=4)
+    cpu = np.zeros((h, w, 4), np.float32)
+    try:
+        _render_all(pta, devs, packed, scene, win, 0, cpu)
+        validations = rd_wf.update_stats()[0]
+        before = _leaf_records(rd_wf)
+        edits = []
+        for i in range(0, 1200, 3):
+            a = np.frombuffer(packed.triangles, np.float32, 12, i * 80).copy()
+            centre = (a[0:3] + a[4:7] + a[8:11]) / np.float32(3)
+            for v in (0, 4, 8):
+                a[v:v + 3] = a[v:v + 3] * np.float32(0.8125) + centre * np.float32(0.1875)
+            edits.append((i * 80, a.tobytes()))
+        assert libm.fesetround(FE_TOWARDZERO) == 0
+        try:
+            for offset, data in edits:
+                rd_wf.buffer_update(d.triangle_buffer, offset, len(data), data)
+        finally:
+            libm.fesetround(FE_TONEAREST)
+        for offset, data in edits:
+            _edit(packed, "triangles", offset, data)
+        _render_all(pta, devs, packed, scene, win, 1, cpu)
+        assert rd_wf.update_stats()[0] == validations, "the edits were to be patched, not re-validated"
+        patched = _leaf_records(rd_wf)
+        assert (patched != before).any(axis=1).sum() >= len(edits) // 2, "the edits did not reach the leaf records"
+        # the same bytes bound anew: the device kernel makes every record
+        d.free_rids()
+        d = wd.PTWorkDispatcher(rd_wf)
+        d.create_buffers(w, h, packed=packed)
+        d.load_shader()
+        devs = [(rd_wf.pinned, rd_wf, d)]
+        _render_all(pta, devs, packed, scene, win, 0, np.zeros((h, w, 4), np.float32))
+        fresh = _leaf_records(rd_wf)
+        assert patched.shape == fresh.shape
+        differ = np.flatnonzero((patched != fresh).any(axis=1))
+        assert differ.size == 0, f"{differ.size} patched leaf records differ from the device's, first at id slot {differ[0]}"
+    finally:
+        d.free_rids()
