@@ -106,3 +106,45 @@ def test_singular_mesh_transform(pta, rd, rd_wf, golden_dir, seed):
         scene = pta.scenes.scene_from_description(desc)
         scene.camera = pta.scene.PTCamera(transform=pta.godot_math.Transform3D.looking_at((1.0, 2.0, 7.0), (0.0, 0.0, 0.0)), fov=60.0)
         _run_case(pta, rd, rd_wf, golden_dir, f"singular{seed}", 160, 96, 5, 4, dispatches=2, scene=scene, bvh_type=int(desc["default_bvh"]))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_degenerate_and_coincident_triangles(pta, rd, rd_wf, golden_dir, seed):
+    """Triangles a leaf's tests have to get right by the letter: zero area (two corners equal, three in a line), exact
+    copies under other materials (equal distance: the later one in the leaf wins), nearly coincident ones, corners so
+    close that the products of their edges are denormal, and corners so far out that they overflow -- in clusters of up
+    to eight, so that they share leaves, long enough to be split between a lane and its helper."""
+    desc, rng = _random_description(3000 + seed)
+    names = [n for n in desc["materials"]]
+    nodes = desc["nodes"]
+
+    def tri(v1, v2, v3, m):
+        return dict(kind="triangle", vertex1=[float(x) for x in v1], vertex2=[float(x) for x in v2], vertex3=[float(x) for x in v3], material=m)
+
+    for _ in range(10):
+        c = rng.uniform(-2.5, 2.5, 3)
+        a, b, d = (c + rng.uniform(-1.0, 1.0, 3) for _ in range(3))
+        kind = int(rng.integers(0, 6))
+        for k in range(int(rng.integers(2, 9))):
+            m = names[int(rng.integers(0, len(names)))]
+            if kind == 0:    # exact copies
+                nodes.append(tri(a, b, d, m))
+            elif kind == 1:  # zero area among real ones
+                nodes.append(tri(a, a, d, m) if k % 3 == 0 else tri(a, (a + d) * 0.5, d, m) if k % 3 == 1 else tri(a, b, d, m))
+            elif kind == 2:  # one float apart
+                nodes.append(tri(np.nextafter(a.astype(np.float32), np.float32(9), dtype=np.float32) if k & 1 else a, b, d, m))
+            elif kind == 3:  # edges whose products are denormal
+                e = np.float32(1e-20)
+                nodes.append(tri(a, a + np.array([e, 0, 0]) * (k + 1), a + np.array([0, e, 0]) * (k + 1), m))
+            elif kind == 4:  # a fan around one edge: equal distances along it
+                nodes.append(tri(a, b, c + rng.uniform(-1.0, 1.0, 3), m))
+            else:            # corners far out: edge products overflow
+                nodes.append(tri(a, a + np.array([3e19, 0, 0]), a + np.array([0, 3e19 * (1 + k), 1.0]), m))
+    with np.errstate(all="ignore"):
+        scene = pta.scenes.scene_from_description(desc)
+        eye = rng.uniform(-1.0, 1.0, 3)
+        eye = eye / np.linalg.norm(eye) * rng.uniform(3.0, 9.0)
+        scene.camera = pta.scene.PTCamera(transform=pta.godot_math.Transform3D.looking_at(tuple(eye.tolist()), (0.0, 0.0, 0.0)),
+                                          fov=float(rng.uniform(40.0, 80.0)))
+        _run_case(pta, rd, rd_wf, golden_dir, f"degenerate{seed}", 160, 96, int(rng.integers(2, 7)), 4, dispatches=2, scene=scene,
+                  bvh_type=int(desc["default_bvh"]))
